@@ -1,0 +1,103 @@
+/*
+ * include/rtc.h -- the C-ABI boundary between the C host and the HIP (gfx950) path tracer.
+ *
+ * The reference (elkiwy/raytraCer) has no plugin/FFI layer: its main() calls camera_get_ray +
+ * ray_color + write_color directly inside an OpenMP loop (03_FullTracer/main.c:137-167).  These entry
+ * points are what a maintainer binds IN PLACE OF that loop; each one names the reference code it
+ * replaces.  Plain C symbols, opaque handles, int status (0 ok, <0 error; text via rtc_last_error()),
+ * no C++/torch types; the caller owns every buffer it passes.  INTEGRATION.md shows the call sequence.
+ *
+ * Device selection: every call acts on the CURRENT HIP device of the calling thread (one process per
+ * GPU; under torch.distributed that is LOCAL_RANK's device).  There is no CPU fallback: with no usable
+ * GPU every compute entry point returns RTC_ERR_DEVICE.
+ */
+#ifndef RAYTRACER_AMD_RTC_H
+#define RAYTRACER_AMD_RTC_H
+
+#include <stddef.h>
+#include <stdint.h>
+#include "raytracer.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { RTC_OK = 0, RTC_ERR_ARG = -1, RTC_ERR_DEVICE = -2, RTC_ERR_SCENE = -3, RTC_ERR_NOMEM = -4 };
+
+typedef struct rtc_scene rtc_scene;
+
+/* Render settings; the defaults of the reference's main() are 1024,1024,256,10 (03 main.c:88-92). */
+typedef struct rtc_settings {
+    int width, height;
+    int max_depth;               /* recursion depth of ray_color: 10 (03 main.c:92), 8 (02 main.c:393) */
+    int sample_begin, sample_end;/* this call renders samples [begin,end) of every pixel: the multi-GPU shard */
+    int integrator;              /* 0 = 03 mixture PDF (ray.c:50-84), 1 = 02 attenuation (02 main.c:44-63), 2 = 01 sky (01 main.c:39-65) */
+    uint64_t seed;               /* Philox key; the reference uses unseeded rand() (utils.h:23) */
+    double mixture_light_weight; /* 0.1 (ray.c:72) */
+    int kernel;                  /* 0 = auto, 1 = persistent-thread megakernel, 2 = wavefront queues */
+    int reserved;
+} rtc_settings;
+
+/* Counters of the last rtc_render* call on this thread's device. */
+typedef struct rtc_stats {
+    uint64_t samples;            /* W*H*(sample_end-sample_begin) */
+    uint64_t rays;               /* closest-hit queries issued by the integrator (ray_color bodies past the depth check) */
+    double   kernel_ms;          /* HIP-event time of the path-tracing kernel(s) on the launch stream */
+    double   total_ms;           /* whole call incl. uploads/downloads */
+    int      kernel_launches;
+    int      kernel_used;        /* 1 megakernel, 2 wavefront */
+} rtc_stats;
+
+/* Probe the current device.  0 when a gfx950-class GPU is usable.  No reference counterpart. */
+int rtc_init(void);
+const char *rtc_last_error(void);
+const char *rtc_device_name(void);
+
+/* Flatten the pointer graph (world list, lights list) into SoA device tables + linear BVH and upload them to the
+ * current device.  Replaces what the reference does implicitly by keeping `world`/`lights` as pointer graphs that
+ * hittable_list_hit walks (hittable_list.c:125-143, hittable.c:595-615).  `background` as main.c:119;
+ * time0/time1 = the camera shutter used for moving-sphere bounds (hittable.c:646-654). */
+rtc_scene *rtc_scene_build(const hittable_list *world, const hittable_list *lights, const color *background,
+                           double time0, double time1);
+/* Host half of rtc_scene_build only (no device, no upload): for inspecting the flattened tables on a machine
+ * without a GPU.  Compute entry points return RTC_ERR_DEVICE for such a handle. */
+rtc_scene *rtc_scene_flatten_only(const hittable_list *world, const hittable_list *lights, const color *background,
+                                  double time0, double time1);
+void rtc_scene_free(rtc_scene *scene);
+/* Number of flattened leaf primitives (visit order of the reference's traversal = primitive id). */
+int  rtc_scene_num_prims(const rtc_scene *scene);
+/* Flattened leaf table for tests: per leaf 16 doubles laid out like oracle/harness.c:hx_dump_leaves. */
+int  rtc_scene_dump_leaves(const rtc_scene *scene, double *out16, int cap);
+
+/* FP64, no-FMA closest hit for n host rays (7 doubles each: orig, dir, time): bit-exact replacement of
+ * hittable_list_hit(world, r, tmin, tmax, &rec) (hittable_list.c:125-143).  prim_id[i] = -1 on miss.
+ * Constant media are stochastic in the reference (hittable.c:574) and are skipped here.
+ * rec12 (optional): hit, t, p(3), normal(3), u, v, front_face, material type -- layout of oracle/harness.c. */
+int rtc_first_hit_f64(const rtc_scene *scene, const double *rays7, size_t n, double tmin, double tmax,
+                      int32_t *prim_id, double *t, double *rec12);
+/* Same, but the rays are generated ON DEVICE from (s,t) screen coordinates exactly as camera_get_ray does
+ * (camera.c:46-53) with the supplied lens sample and time: lens3 = unit-disk point (x,y) and ray time per ray
+ * (NULL = no lens offset, time 0).  rays7_out (optional) returns the generated rays. */
+int rtc_primary_first_hit_f64(const rtc_scene *scene, const camera *cam, const double *st2, const double *lens3,
+                              size_t n, double tmin, double tmax, int32_t *prim_id, double *t, double *rays7_out);
+
+/* The hot path: replaces the pixel/sample loop of 03 main.c:137-160 (camera_get_ray + ray_color + sum).
+ * accum_rgba is W*H float4 = (sum R, sum G, sum B, sample count), row j=0 at the BOTTOM like the reference's
+ * pixel index (main.c:157); the call ADDS to it, so successive calls with disjoint sample ranges accumulate
+ * progressively.  rtc_render_device takes a DEVICE pointer (e.g. a torch tensor's data_ptr) and enqueues on
+ * `stream` (a hipStream_t, NULL = default stream) without synchronising; rtc_render takes a HOST buffer. */
+int rtc_render_device(const rtc_scene *scene, const camera *cam, const rtc_settings *settings,
+                      float *accum_rgba_device, void *stream);
+int rtc_render(const rtc_scene *scene, const camera *cam, const rtc_settings *settings, float *accum_rgba_host);
+/* Blocks until the last rtc_render_device on `stream` has finished and fills the counters. */
+int rtc_render_stats(const rtc_scene *scene, void *stream, rtc_stats *out);
+
+/* write_color (ray.c:35-47): rgb/count -> sqrt -> clamp [0,0.999] -> *256 -> u8, for every pixel, on device.
+ * rgb_u8 is W*H*3, same row order as accum (flip at PNG time like main.c:170). Non-finite sums map to 0. */
+int rtc_tonemap_u8_device(const float *accum_rgba_device, int width, int height, unsigned char *rgb_u8_device, void *stream);
+int rtc_tonemap_u8(const float *accum_rgba_host, int width, int height, unsigned char *rgb_u8_host);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

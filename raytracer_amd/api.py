@@ -1,0 +1,264 @@
+"""ctypes mirror of include/raytracer.h and include/rtc.h (host-side plumbing, not the product).
+
+Names, argument meaning and error behaviour follow the C headers, which in turn follow the reference's
+scene-construction API (03_FullTracer/hittable.h:117-129, material.h:39-52, texture.h:56-68, camera.h:29-35).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+class RtcError(RuntimeError):
+    pass
+
+
+def library_path():
+    return os.path.join(_HERE, "librtc.so")
+
+
+class Vec3(C.Structure):
+    _fields_ = [("x", C.c_double), ("y", C.c_double), ("z", C.c_double)]
+
+
+def v3(a):
+    return Vec3(float(a[0]), float(a[1]), float(a[2]))
+
+
+class SceneView(C.Structure):
+    _fields_ = [("lookfrom", Vec3), ("lookat", Vec3), ("vup", Vec3), ("vfov", C.c_double), ("aspect", C.c_double),
+                ("aperture", C.c_double), ("focus_dist", C.c_double), ("time0", C.c_double), ("time1", C.c_double),
+                ("background", Vec3), ("integrator", C.c_int), ("max_depth", C.c_int)]
+
+
+class RtcSettings(C.Structure):
+    _fields_ = [("width", C.c_int), ("height", C.c_int), ("max_depth", C.c_int), ("sample_begin", C.c_int),
+                ("sample_end", C.c_int), ("integrator", C.c_int), ("seed", C.c_uint64),
+                ("mixture_light_weight", C.c_double), ("kernel", C.c_int), ("reserved", C.c_int)]
+
+
+class RtcStats(C.Structure):
+    _fields_ = [("samples", C.c_uint64), ("rays", C.c_uint64), ("kernel_ms", C.c_double), ("total_ms", C.c_double),
+                ("kernel_launches", C.c_int), ("kernel_used", C.c_int)]
+
+
+SCENES = dict(simple=0, cornell=1, final=2, book1=3, cornell02=4, cornell_smoke=5, two_spheres=6, two_perlin=7,
+              simple_light=8, book2_random=9, million=10)
+
+_P = C.c_void_p
+_dp = C.POINTER(C.c_double)
+
+# every symbol include/raytracer.h and include/rtc.h declare (checked by tests/test_abi.py)
+HOST_SYMBOLS = """random_double random_double_scaled random_int deg2rad texture_solid_color_init
+texture_solid_color_init_rgb texture_checker_init texture_checker_init_c texture_noise_init_scaled texture_noise_init
+texture_image_init texture_image_init_rgb textures_free_all material_lambertian_new material_lambertian_new_from_color
+material_metal_new material_dielectric_new material_light_new material_light_new_from_color material_isotropic_new
+material_isotropic_new_from_color materials_free_all hittable_list_new hittable_list_new_no_gc hittable_list_add
+hittable_list_index hittable_list_objects hittable_list_free hittable_lists_free_all hittable_sphere_new
+hittable_rect_new hittable_box_new hittable_moving_sphere_new bvh_node_init hittable_translate_init
+hittable_rotate_init hittable_constant_medium_init hittable_constant_medium_init_c hittable_flip_face_init
+hittable_free camera_new camera_free camera_fields rt_scene_build rt_write_png rt_write_ppm_p3""".split()
+RTC_SYMBOLS = """rtc_init rtc_last_error rtc_device_name rtc_scene_build rtc_scene_flatten_only rtc_scene_free rtc_scene_num_prims
+rtc_scene_dump_leaves rtc_first_hit_f64 rtc_primary_first_hit_f64 rtc_render_device rtc_render rtc_render_stats
+rtc_tonemap_u8_device rtc_tonemap_u8""".split()
+
+
+def lib():
+    """Load librtc.so once and declare signatures.  Raises if the HIP extension was not built."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = library_path()
+    if not os.path.exists(path):
+        raise RtcError(f"{path} is missing: build it with `make -C raytracer_amd/csrc` (no CPU fallback exists)")
+    L = C.CDLL(path)
+    for name in ("texture_solid_color_init", "texture_checker_init", "texture_noise_init_scaled", "texture_image_init_rgb",
+                 "material_lambertian_new", "material_lambertian_new_from_color", "material_metal_new",
+                 "material_dielectric_new", "material_light_new", "material_light_new_from_color",
+                 "material_isotropic_new", "hittable_list_new", "hittable_list_new_no_gc", "hittable_sphere_new",
+                 "hittable_rect_new", "hittable_box_new", "hittable_moving_sphere_new", "bvh_node_init",
+                 "hittable_translate_init", "hittable_rotate_init", "hittable_constant_medium_init_c",
+                 "hittable_flip_face_init", "camera_new", "rt_scene_build", "rtc_scene_build", "rtc_scene_flatten_only"):
+        getattr(L, name).restype = _P
+    L.texture_solid_color_init.argtypes = [Vec3]
+    L.texture_checker_init.argtypes = [_P, _P]
+    L.texture_noise_init_scaled.argtypes = [C.c_double]
+    L.texture_image_init_rgb.argtypes = [_P, C.c_int, C.c_int]
+    L.material_lambertian_new.argtypes = [_P]
+    L.material_lambertian_new_from_color.argtypes = [Vec3]
+    L.material_metal_new.argtypes = [Vec3, C.c_double]
+    L.material_dielectric_new.argtypes = [C.c_double]
+    L.material_light_new.argtypes = [_P]
+    L.material_light_new_from_color.argtypes = [Vec3]
+    L.material_isotropic_new.argtypes = [_P]
+    L.hittable_list_new.argtypes = [C.c_int]
+    L.hittable_list_new_no_gc.argtypes = [C.c_int]
+    L.hittable_list_add.argtypes = [_P, _P]
+    L.hittable_list_index.argtypes = [_P]
+    L.hittable_sphere_new.argtypes = [_P, Vec3, C.c_double, _P]
+    L.hittable_rect_new.argtypes = [_P] + [C.c_double] * 7 + [C.c_int, _P]
+    L.hittable_box_new.argtypes = [_P, Vec3, Vec3, _P]
+    L.hittable_moving_sphere_new.argtypes = [_P, Vec3, Vec3, C.c_double, C.c_double, C.c_double, _P]
+    L.bvh_node_init.argtypes = [_P, _P, C.c_double, C.c_double]
+    L.hittable_translate_init.argtypes = [_P, _P, Vec3]
+    L.hittable_rotate_init.argtypes = [_P, _P, C.c_double, C.c_int]
+    L.hittable_constant_medium_init_c.argtypes = [_P, _P, C.c_double, Vec3]
+    L.hittable_flip_face_init.argtypes = [_P, _P]
+    L.camera_new.argtypes = [Vec3, Vec3, Vec3] + [C.c_double] * 6
+    L.camera_free.argtypes = [_P]
+    L.camera_fields.argtypes = [_P, _dp]
+    L.rt_scene_build.argtypes = [C.c_int, C.c_int, _P, C.POINTER(SceneView)]
+    L.rt_write_png.argtypes = [C.c_char_p, C.c_int, C.c_int, _P, C.c_int]
+    L.rt_write_ppm_p3.argtypes = [C.c_char_p, C.c_int, C.c_int, _P, C.c_int]
+    L.rtc_last_error.restype = C.c_char_p
+    L.rtc_device_name.restype = C.c_char_p
+    L.rtc_scene_build.argtypes = [_P, _P, C.POINTER(Vec3), C.c_double, C.c_double]
+    L.rtc_scene_flatten_only.argtypes = [_P, _P, C.POINTER(Vec3), C.c_double, C.c_double]
+    L.rtc_scene_free.argtypes = [_P]
+    L.rtc_scene_num_prims.argtypes = [_P]
+    L.rtc_scene_dump_leaves.argtypes = [_P, _dp, C.c_int]
+    L.rtc_first_hit_f64.argtypes = [_P, _dp, C.c_size_t, C.c_double, C.c_double, _P, _dp, _dp]
+    L.rtc_primary_first_hit_f64.argtypes = [_P, _P, _dp, _dp, C.c_size_t, C.c_double, C.c_double, _P, _dp, _dp]
+    L.rtc_render_device.argtypes = [_P, _P, C.POINTER(RtcSettings), _P, _P]
+    L.rtc_render.argtypes = [_P, _P, C.POINTER(RtcSettings), _P]
+    L.rtc_render_stats.argtypes = [_P, _P, C.POINTER(RtcStats)]
+    L.rtc_tonemap_u8_device.argtypes = [_P, C.c_int, C.c_int, _P, _P]
+    L.rtc_tonemap_u8.argtypes = [_P, C.c_int, C.c_int, _P]
+    L.srand = C.CDLL(None).srand
+    _LIB = L
+    return L
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise RtcError(f"{what}: {lib().rtc_last_error().decode()} (code {rc})")
+
+
+def rtc_init():
+    _check(lib().rtc_init(), "rtc_init")
+    return lib().rtc_device_name().decode()
+
+
+class Settings:
+    """Mirror of rtc_settings; defaults are the reference's (03 main.c:88-92, ray.c:72)."""
+
+    def __init__(self, width=1024, height=1024, spp=256, max_depth=10, integrator=0, seed=0, sample_begin=0,
+                 sample_end=None, mixture_light_weight=0.1, kernel=0):
+        self.c = RtcSettings(width, height, max_depth, sample_begin, spp if sample_end is None else sample_end,
+                             integrator, seed, mixture_light_weight, kernel, 0)
+
+
+class Camera:
+    def __init__(self, lookfrom, lookat, vup, vfov, aspect, aperture, focus_dist, time0=0.0, time1=1.0):
+        self.handle = lib().camera_new(v3(lookfrom), v3(lookat), v3(vup), vfov, aspect, aperture, focus_dist, time0, time1)
+
+    @classmethod
+    def from_view(cls, view, aspect=None):
+        g = lambda v: (v.x, v.y, v.z)
+        return cls(g(view.lookfrom), g(view.lookat), g(view.vup), view.vfov, aspect or view.aspect, view.aperture,
+                   view.focus_dist, view.time0, view.time1)
+
+    def fields(self):
+        out = np.zeros(24)
+        lib().camera_fields(self.handle, out.ctypes.data_as(_dp))
+        return out
+
+
+class Scene:
+    """A flattened scene resident on the current HIP device (rtc_scene)."""
+
+    def __init__(self, world, lights, background=(0, 0, 0), time0=0.0, time1=1.0, view=None, host_only=False):
+        bg = v3(background)
+        self.world, self.lights, self.view = world, lights, view
+        build = lib().rtc_scene_flatten_only if host_only else lib().rtc_scene_build
+        self.handle = build(world, lights, C.byref(bg), time0, time1)
+        if not self.handle:
+            raise RtcError("rtc_scene_build: " + lib().rtc_last_error().decode())
+
+    def close(self):
+        if self.handle:
+            lib().rtc_scene_free(self.handle)
+            self.handle = None
+
+    def num_prims(self):
+        return lib().rtc_scene_num_prims(self.handle)
+
+    def dump_leaves(self):
+        n = self.num_prims()
+        out = np.zeros((max(n, 1), 16))
+        lib().rtc_scene_dump_leaves(self.handle, out.ctypes.data_as(_dp), n)
+        return out[:n]
+
+    def first_hit(self, rays7, tmin=0.001, tmax=np.inf, want_rec=False):
+        rays7 = np.ascontiguousarray(rays7, dtype=np.float64)
+        n = rays7.size // 7
+        prim = np.zeros(n, dtype=np.int32)
+        t = np.zeros(n)
+        rec = np.zeros((n, 12)) if want_rec else None
+        _check(lib().rtc_first_hit_f64(self.handle, rays7.ctypes.data_as(_dp), n, tmin, tmax, prim.ctypes.data, t.ctypes.data_as(_dp),
+                                       rec.ctypes.data_as(_dp) if want_rec else None), "rtc_first_hit_f64")
+        return (prim, t, rec) if want_rec else (prim, t)
+
+    def primary_first_hit(self, cam, st2, lens3=None, tmin=0.001, tmax=np.inf):
+        st2 = np.ascontiguousarray(st2, dtype=np.float64)
+        n = st2.size // 2
+        prim = np.zeros(n, dtype=np.int32)
+        t = np.zeros(n)
+        rays = np.zeros((n, 7))
+        lp = None
+        if lens3 is not None:
+            lens3 = np.ascontiguousarray(lens3, dtype=np.float64)
+            lp = lens3.ctypes.data_as(_dp)
+        _check(lib().rtc_primary_first_hit_f64(self.handle, cam.handle, st2.ctypes.data_as(_dp), lp, n, tmin, tmax, prim.ctypes.data,
+                                               t.ctypes.data_as(_dp), rays.ctypes.data_as(_dp)), "rtc_primary_first_hit_f64")
+        return prim, t, rays
+
+    def render(self, cam, settings, accum=None):
+        """Host-buffer render: returns (accum[h, w, 4] float32 with row 0 = bottom, stats dict)."""
+        s = settings.c
+        if accum is None:
+            accum = np.zeros((s.height, s.width, 4), dtype=np.float32)
+        _check(lib().rtc_render(self.handle, cam.handle, C.byref(s), accum.ctypes.data), "rtc_render")
+        return accum, self.stats(None)
+
+    def render_device(self, cam, settings, accum_ptr, stream=None):
+        _check(lib().rtc_render_device(self.handle, cam.handle, C.byref(settings.c), accum_ptr, stream), "rtc_render_device")
+
+    def stats(self, stream=None):
+        st = RtcStats()
+        _check(lib().rtc_render_stats(self.handle, stream, C.byref(st)), "rtc_render_stats")
+        return dict(samples=st.samples, rays=st.rays, kernel_ms=st.kernel_ms, total_ms=st.total_ms,
+                    kernel_launches=st.kernel_launches, kernel_used=st.kernel_used)
+
+
+def build_named_scene(name, arg=0, aspect=None, seed=1, host_only=False):
+    """srand(seed); rt_scene_build(...) -> (Scene, Camera, SceneView).  Scene ids as in raytracer.h."""
+    L = lib()
+    L.srand(C.c_uint(seed))
+    lights = L.hittable_list_new_no_gc(64)
+    view = SceneView()
+    world = L.rt_scene_build(SCENES[name] if isinstance(name, str) else name, arg, lights, C.byref(view))
+    if not world:
+        raise RtcError(f"unknown scene {name}")
+    cam = Camera.from_view(view, aspect)
+    scene = Scene(world, lights, (view.background.x, view.background.y, view.background.z), view.time0, view.time1, view,
+                  host_only=host_only)
+    return scene, cam, view
+
+
+def tonemap_u8(accum):
+    accum = np.ascontiguousarray(accum, dtype=np.float32)
+    h, w = accum.shape[:2]
+    out = np.zeros((h, w, 3), dtype=np.uint8)
+    _check(lib().rtc_tonemap_u8(accum.ctypes.data, w, h, out.ctypes.data), "rtc_tonemap_u8")
+    return out
+
+
+def png_write(path, rgb_u8, flip=True):
+    rgb_u8 = np.ascontiguousarray(rgb_u8, dtype=np.uint8)
+    h, w = rgb_u8.shape[:2]
+    if lib().rt_write_png(path.encode(), w, h, rgb_u8.ctypes.data, int(flip)) != 1:
+        raise RtcError(f"rt_write_png({path}) failed")

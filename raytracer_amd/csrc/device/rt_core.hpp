@@ -1,0 +1,249 @@
+// rt_core.hpp -- geometry half of the hot path for gfx950 (product code, device only).
+//
+// Templated on the real type: R = double instantiates the bit-exact check path (built with -ffp-contract=off so
+// no mul+add pair is fused; IEEE / and sqrt), R = float the production path (contraction on, v_rcp/v_rsq/v_sqrt).
+// The FP64 instantiation reproduces the operation order of the reference's hit functions; citations are
+// file:line under /root/reference/03_FullTracer/.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "../rtc_tables.h"
+
+#define RT_DEV __device__ __forceinline__
+
+template <typename R> struct V3 { R x, y, z; };
+template <typename R> RT_DEV V3<R> mk3(R x, R y, R z) { V3<R> v; v.x = x; v.y = y; v.z = z; return v; }
+template <typename R> RT_DEV V3<R> operator+(V3<R> a, V3<R> b) { return mk3<R>(a.x + b.x, a.y + b.y, a.z + b.z); }
+template <typename R> RT_DEV V3<R> operator-(V3<R> a, V3<R> b) { return mk3<R>(a.x - b.x, a.y - b.y, a.z - b.z); }
+template <typename R> RT_DEV V3<R> operator*(V3<R> a, V3<R> b) { return mk3<R>(a.x * b.x, a.y * b.y, a.z * b.z); }
+template <typename R> RT_DEV V3<R> operator*(V3<R> a, R k) { return mk3<R>(a.x * k, a.y * k, a.z * k); }
+template <typename R> RT_DEV V3<R> operator-(V3<R> a) { return mk3<R>(-a.x, -a.y, -a.z); }
+template <typename R> RT_DEV R dot(V3<R> a, V3<R> b) { return a.x * b.x + a.y * b.y + a.z * b.z; }          // vec3.c:22, left to right
+template <typename R> RT_DEV R len2(V3<R> a) { return (a.x * a.x) + (a.y * a.y) + (a.z * a.z); }          // vec3.c:21
+template <typename R> RT_DEV V3<R> cross(V3<R> a, V3<R> b) { return mk3<R>(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+
+// Math traits: exact for double, fast hardware approximations (<= 1 ulp) for float.
+template <typename R> struct Mth;
+template <> struct Mth<double> {
+    static RT_DEV double div(double a, double b) { return a / b; }
+    static RT_DEV double sqrt(double a) { return ::sqrt(a); }
+    static RT_DEV double inf() { return __builtin_huge_val(); }
+};
+template <> struct Mth<float> {
+    static RT_DEV float div(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
+    static RT_DEV float sqrt(float a) { return __builtin_amdgcn_sqrtf(a); }
+    static RT_DEV float inf() { return __builtin_huge_valf(); }
+};
+template <typename R> RT_DEV V3<R> divk(V3<R> a, R k) { return mk3<R>(Mth<R>::div(a.x, k), Mth<R>::div(a.y, k), Mth<R>::div(a.z, k)); }  // vec3.c:19 (true division, F12)
+template <typename R> RT_DEV R length(V3<R> a) { return Mth<R>::sqrt(len2(a)); }
+template <typename R> RT_DEV V3<R> unit(V3<R> a) { return divk(a, length(a)); }
+
+template <typename R> struct RayT { V3<R> o, d; R time; };
+
+// rotatePoint (hittable.c:37-48): writes two components, keeps the third (axis naming quirk F10)
+template <typename R> RT_DEV V3<R> rot(V3<R> p, R s, R c, int axis) {
+    V3<R> q = p;
+    if (axis == RTC_ROT_X) { q.x = c * p.x - s * p.y; q.y = s * p.x + c * p.y; }
+    else if (axis == RTC_ROT_Y) { q.x = c * p.x + s * p.z; q.z = -s * p.x + c * p.z; }
+    else { q.y = c * p.y - s * p.z; q.z = s * p.y + c * p.z; }
+    return q;
+}
+
+// Enter the first `upto` wrappers of a chain, outermost first: translate_hit (:529) moves the origin,
+// rotate_hit (:542-545) rotates origin and direction with (-sin, cos); flip_face leaves the ray alone.
+template <typename R> RT_DEV RayT<R> chain_enter(const SceneT<R> &sc, int chain, RayT<R> r, int upto = 1 << 30) {
+    const ChainRange cr = sc.chains[chain];
+    const int n = cr.count < upto ? cr.count : upto;
+    for (int i = 0; i < n; ++i) {
+        const OpT<R> op = sc.ops[cr.first + i];
+        if (op.type == RTC_OP_TRANSLATE) r.o = r.o - mk3<R>(op.a, op.b, op.c);
+        else if (op.type == RTC_OP_ROTATE) { r.o = rot(r.o, -op.a, op.b, op.axis); r.d = rot(r.d, -op.a, op.b, op.axis); }
+    }
+    return r;
+}
+
+// Candidate parameter of one leaf for a ray already in the leaf's space: the first root inside [tmin, tmax]
+// exactly as line_sphere_intersection (:406-429) / rect_hit (:494-506) accept it.
+template <typename R> RT_DEV bool sphere_t(V3<R> center, R rad, const RayT<R> &r, R tmin, R tmax, R &t_out) {
+    const V3<R> oc = r.o - center;
+    const R a = len2(r.d), half_b = dot(oc, r.d), c = len2(oc) - rad * rad;
+    const R disc = half_b * half_b - a * c;
+    if (disc < 0) return false;
+    const R sq = Mth<R>::sqrt(disc);
+    R t = Mth<R>::div(-half_b - sq, a);
+    if (t < tmin || t > tmax) { t = Mth<R>::div(-half_b + sq, a); if (t < tmin || t > tmax) return false; }
+    t_out = t; return true;
+}
+template <typename R> RT_DEV V3<R> msphere_center(const R *d, R time) {  // moving_sphere_center :455-458
+    const R k = Mth<R>::div(time - d[6], d[7] - d[6]);
+    return mk3<R>((d[3] - d[0]) * k + d[0], (d[4] - d[1]) * k + d[1], (d[5] - d[2]) * k + d[2]);
+}
+template <typename R> RT_DEV bool rect_t(const R *d, int axis, const RayT<R> &r, R tmin, R tmax, R &t_out) {
+    R t;
+    if (axis == RTC_AXIS_XY) t = Mth<R>::div(d[6] - r.o.z, r.d.z);
+    else if (axis == RTC_AXIS_XZ) t = Mth<R>::div(d[6] - r.o.y, r.d.y);
+    else t = Mth<R>::div(d[6] - r.o.x, r.d.x);
+    if (t < tmin || t > tmax) return false;   // a NaN t passes, like the reference (F20)
+    const R x = r.o.x + t * r.d.x, y = r.o.y + t * r.d.y, z = r.o.z + t * r.d.z;
+    if (axis == RTC_AXIS_XZ) { if (x < d[0] || x > d[1] || z < d[4] || z > d[5]) return false; }
+    else if (axis == RTC_AXIS_XY) { if (x < d[0] || x > d[1] || y < d[2] || y > d[3]) return false; }
+    else { if (z < d[4] || z > d[5] || y < d[2] || y > d[3]) return false; }
+    t_out = t; return true;
+}
+template <typename R> RT_DEV bool leaf_t(const PrimT<R> &p, const RayT<R> &rl, R tmin, R tmax, R &t) {
+    if (p.type == RTC_PRIM_RECT) return rect_t(p.d, p.axis, rl, tmin, tmax, t);
+    if (p.type == RTC_PRIM_SPHERE) return sphere_t(mk3<R>(p.d[0], p.d[1], p.d[2]), p.d[3], rl, tmin, tmax, t);
+    if (p.type == RTC_PRIM_MSPHERE) return sphere_t(msphere_center(p.d, rl.time), p.d[8], rl, tmin, tmax, t);
+    return false;
+}
+
+template <typename R> struct HitT { R t; int prim; };
+
+// hittable_list_hit (hittable_list.c:125-143) over the flattened leaves in visit order: `t > closest` rejects,
+// so an equal t on a later leaf replaces the earlier one.  `prim` is wave-uniform, so the table reads are scalar.
+// Media are handled by the caller-supplied functor (stochastic in the reference, hittable.c:563-584).
+template <typename R, typename MediumFn>
+RT_DEV HitT<R> closest_hit_range(const SceneT<R> &sc, const PrimT<R> *prims, int first, int count, const RayT<R> &r, R tmin, R tmax, MediumFn &&medium) {
+    HitT<R> h; h.t = tmax; h.prim = -1;
+    int cur_chain = 0; RayT<R> rl = r;
+    for (int i = first; i < first + count; ++i) {
+        const PrimT<R> &p = prims[i];
+        R t;
+        if (p.type == RTC_PRIM_MEDIUM) { if (medium(i, h.t, t)) { h.t = t; h.prim = i; } continue; }
+        if (p.chain != cur_chain) { cur_chain = p.chain; rl = chain_enter(sc, cur_chain, r); }
+        if (leaf_t(p, rl, tmin, h.t, t)) { h.t = t; h.prim = i; }
+    }
+    return h;
+}
+template <typename R, typename MediumFn>
+RT_DEV HitT<R> closest_hit_linear(const SceneT<R> &sc, const RayT<R> &r, R tmin, R tmax, MediumFn &&medium) {
+    return closest_hit_range<R>(sc, sc.prims, 0, sc.n_prims, r, tmin, tmax, medium);
+}
+
+// Same result from the linear BVH: any visiting order, so ties are broken explicitly -- the leaf with the
+// highest visit-order index wins, which is what the reference's left-then-right scan produces.
+template <typename R> RT_DEV bool slab(const float *lo, const float *hi, V3<R> o, V3<R> inv, R tmin, R tmax) {
+    R t0 = ((R)lo[0] - o.x) * inv.x, t1 = ((R)hi[0] - o.x) * inv.x;
+    R tn = t0 < t1 ? t0 : t1, tf = t0 < t1 ? t1 : t0;
+    t0 = ((R)lo[1] - o.y) * inv.y; t1 = ((R)hi[1] - o.y) * inv.y;
+    R a = t0 < t1 ? t0 : t1, b = t0 < t1 ? t1 : t0;
+    tn = a > tn ? a : tn; tf = b < tf ? b : tf;
+    t0 = ((R)lo[2] - o.z) * inv.z; t1 = ((R)hi[2] - o.z) * inv.z;
+    a = t0 < t1 ? t0 : t1; b = t0 < t1 ? t1 : t0;
+    tn = a > tn ? a : tn; tf = b < tf ? b : tf;
+    tn = tn > tmin ? tn : tmin; tf = tf < tmax ? tf : tmax;
+    // boxes are padded outward at build time; the extra slack covers the rounding of this test itself.
+    // NaN (0 * inf on a degenerate axis) compares false everywhere and therefore keeps the node.
+    return !(tn > tf * (R)1.0000001 + (R)1e-7);
+}
+// Traversal stacks: a private array for the FP64 check kernel, an LDS column per lane for the FP32 path tracer
+// (entry e of lane l lives at base[e * stride + l]: consecutive lanes hit consecutive banks).
+struct LocalStack {
+    int v[48]; int sp = 0;
+    RT_DEV void push(int x) { if (sp < 48) v[sp++] = x; }
+    RT_DEV bool pop(int &x) { if (sp == 0) return false; x = v[--sp]; return true; }
+};
+struct LdsStack {
+    int *base; int stride, cap; int sp = 0;
+    RT_DEV LdsStack(int *b, int s, int c) : base(b), stride(s), cap(c) {}
+    RT_DEV void push(int x) { if (sp < cap) { base[sp * stride] = x; ++sp; } }
+    RT_DEV bool pop(int &x) { if (sp == 0) return false; --sp; x = base[sp * stride]; return true; }
+};
+template <typename R, typename Stack, typename MediumFn>
+RT_DEV HitT<R> closest_hit_bvh(const SceneT<R> &sc, const RayT<R> &r, R tmin, R tmax, Stack &stack, MediumFn &&medium) {
+    HitT<R> h; h.t = tmax; h.prim = -1;
+    const V3<R> inv = mk3<R>(Mth<R>::div((R)1, r.d.x), Mth<R>::div((R)1, r.d.y), Mth<R>::div((R)1, r.d.z));
+    int node = 0;
+    for (;;) {
+        const BvhNode nd = sc.nodes[node];
+        const bool h0 = slab<R>(nd.lo0, nd.hi0, r.o, inv, tmin, h.t), h1 = slab<R>(nd.lo1, nd.hi1, r.o, inv, tmin, h.t);
+        int next = -1;
+        // leaves first (they can only shrink h.t), then descend
+        for (int side = 0; side < 2; ++side) {
+            const bool hs = side ? h1 : h0; const int cnt = side ? nd.count1 : nd.count0; const int ch = side ? nd.child1 : nd.child0;
+            if (!hs) continue;
+            if (cnt > 0) {
+                for (int k = 0; k < cnt; ++k) {
+                    const int id = sc.leaf_prims[ch + k];
+                    const PrimT<R> &p = sc.prims[id];
+                    R t;
+                    if (p.type == RTC_PRIM_MEDIUM) { if (medium(id, h.t, t) && !(t == h.t && id < h.prim)) { h.t = t; h.prim = id; } continue; }
+                    const RayT<R> rl = p.chain ? chain_enter(sc, p.chain, r) : r;
+                    if (leaf_t(p, rl, tmin, h.t, t) && !(t == h.t && id < h.prim)) { h.t = t; h.prim = id; }
+                }
+            } else if (next < 0) next = ch;
+            else stack.push(ch);
+        }
+        if (next >= 0) { node = next; continue; }
+        if (!stack.pop(node)) break;
+    }
+    return h;
+}
+
+// Full hit record of the winning leaf: sphere_hit (:440-445) / rect_hit (:509-515), then the wrappers inside-out:
+// rotate_hit (:552-557) turns p and normal back with (+sin, cos) and re-faces the normal against the OBJECT-space
+// direction (F11), translate_hit (:533-534) shifts p and re-faces against its own ray, flip_face (:589) toggles
+// front_face only.
+template <typename R> struct RecT { V3<R> p, n; R u, v; int front, mat; };
+template <typename R> RT_DEV void face(RecT<R> &rec, V3<R> dir, V3<R> outward) {
+    rec.front = dot(dir, outward) < 0;
+    rec.n = rec.front ? outward : -outward;
+}
+template <typename R> RT_DEV void sphere_uv(V3<R> n, R &u, R &v);
+template <> RT_DEV void sphere_uv<double>(V3<double> n, double &u, double &v) {   // :381-386
+    const double PI_ = 3.1415926535897932385;
+    const double theta = ::acos(-n.y), phi = ::atan2(-n.z, n.x) + PI_;
+    u = phi / (2 * PI_); v = theta / PI_;
+}
+template <> RT_DEV void sphere_uv<float>(V3<float> n, float &u, float &v) {
+    const float PI_ = 3.14159265358979f;
+    const float theta = acosf(fminf(fmaxf(-n.y, -1.f), 1.f)), phi = atan2f(-n.z, n.x) + PI_;
+    u = phi * (0.5f / PI_); v = theta * (1.f / PI_);
+}
+template <typename R> RT_DEV RecT<R> resolve_hit(const SceneT<R> &sc, const RayT<R> &r, const PrimT<R> &p, R t, bool want_uv) {
+    RecT<R> rec; rec.mat = p.mat; rec.u = 0; rec.v = 0;
+    const RayT<R> rl = chain_enter(sc, p.chain, r);
+    rec.p = rl.o + rl.d * t;                                   // ray_at, ray.c:8-11
+    if (p.type == RTC_PRIM_RECT) {
+        if (want_uv) {
+            const R x = rec.p.x, y = rec.p.y, z = rec.p.z; const R *d = p.d;
+            rec.u = p.axis == RTC_AXIS_YZ ? Mth<R>::div(y - d[2], d[3] - d[2]) : Mth<R>::div(x - d[0], d[1] - d[0]);
+            rec.v = p.axis == RTC_AXIS_XY ? Mth<R>::div(y - d[2], d[3] - d[2]) : Mth<R>::div(z - d[4], d[5] - d[4]);
+        }
+        face(rec, rl.d, mk3<R>(p.axis == RTC_AXIS_YZ ? 1 : 0, p.axis == RTC_AXIS_XZ ? 1 : 0, p.axis == RTC_AXIS_XY ? 1 : 0));
+    } else if (p.type == RTC_PRIM_MEDIUM) {                    // constant_medium_hit :578-582
+        rec.n = mk3<R>(1, 0, 0); rec.front = 1;
+    } else {
+        const V3<R> c = p.type == RTC_PRIM_SPHERE ? mk3<R>(p.d[0], p.d[1], p.d[2]) : msphere_center(p.d, rl.time);
+        const R rad = p.type == RTC_PRIM_SPHERE ? p.d[3] : p.d[8];
+        const V3<R> outward = divk(rec.p - c, rad);
+        face(rec, rl.d, outward);
+        if (want_uv) sphere_uv<R>(outward, rec.u, rec.v);
+    }
+    const ChainRange cr = sc.chains[p.chain];
+    for (int i = cr.count - 1; i >= 0; --i) {
+        const OpT<R> op = sc.ops[cr.first + i];
+        if (op.type == RTC_OP_FLIP) { rec.front = !rec.front; continue; }
+        if (op.type == RTC_OP_ROTATE) {
+            const RayT<R> ri = chain_enter(sc, p.chain, r, i + 1);   // the rotated_ray of this wrapper, bit for bit
+            rec.p = rot(rec.p, op.a, op.b, op.axis);
+            face(rec, ri.d, rot(rec.n, op.a, op.b, op.axis));
+        } else {
+            const RayT<R> ri = chain_enter(sc, p.chain, r, i);       // direction seen by this translate
+            rec.p = rec.p + mk3<R>(op.a, op.b, op.c);
+            face(rec, ri.d, rec.n);
+        }
+    }
+    return rec;
+}
+
+// camera_get_ray (camera.c:46-53) for a supplied unit-disk sample and time.
+template <typename R> RT_DEV RayT<R> camera_ray(const CameraT<R> &c, R s, R t, R disk_x, R disk_y, R time) {
+    auto L = [](const R *a) { return mk3<R>(a[0], a[1], a[2]); };
+    const V3<R> rd = mk3<R>(disk_x, disk_y, (R)0) * c.lens_radius;
+    const V3<R> offset = L(c.u) * rd.x + L(c.v) * rd.y;
+    V3<R> dir = ((L(c.llc) + L(c.horizontal) * s) + L(c.vertical) * t) - L(c.origin);
+    dir = dir - offset;
+    RayT<R> r; r.o = L(c.origin) + offset; r.d = dir; r.time = time;
+    return r;
+}

@@ -1,0 +1,260 @@
+// rt_shade.hpp -- shading half of the hot path, FP32, gfx950 (product code, device only).
+//
+// Switch-dispatched restatement of the reference's material / pdf / onb / texture maths
+// (material.c, pdf.c, onb.c, texture.c, perlin.c under /root/reference/03_FullTracer and
+// 02_AdvancedTracer/src/material.c for integrator 1/2).  rand() is replaced by Philox4x32-10 keyed on
+// (pixel, sample, bounce); rejection loops (vec3.c:66-72,87-93) are replaced by analytic samplers with the same
+// distribution (uniform ball / uniform disk), which is what image-level parity needs.
+#pragma once
+#include "rt_core.hpp"
+
+typedef V3<float> f3;
+#define RT_PI 3.14159265358979323846f
+#define RT_INV_PI 0.31830988618379067154f
+
+// ---- Philox4x32-10 (Salmon et al., SC'11) --------------------------------------------------------
+struct U4 { uint32_t x, y, z, w; };
+RT_DEV U4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        c1 = (uint32_t)p1; c3 = (uint32_t)p0; c0 = n0; c2 = n2;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    U4 o; o.x = c0; o.y = c1; o.z = c2; o.w = c3; return o;
+}
+RT_DEV float u01(uint32_t x) { return (float)(x >> 8) * (1.0f / 16777216.0f); }   // [0,1), 24 bits
+struct Rng4 { float x, y, z, w; };
+// stream tags (counter word 2): bounce b -> b ; camera -> 0xFFFFFFFF ; shutter time -> 0xFFFFFFFE ; media -> 0x80000000|...
+#define RT_TAG_CAMERA 0xFFFFFFFFu
+#define RT_TAG_TIME 0xFFFFFFFEu
+#define RT_TAG_MEDIA 0x80000000u
+RT_DEV Rng4 rng_block(uint32_t pixel, uint32_t sample, uint32_t tag, uint32_t k0, uint32_t k1) {
+    const U4 b = philox4x32_10(pixel, sample, tag, 0x52544331u /* "RTC1" */, k0, k1);
+    Rng4 r; r.x = u01(b.x); r.y = u01(b.y); r.z = u01(b.z); r.w = u01(b.w); return r;
+}
+
+// ---- small maths ---------------------------------------------------------------------------------
+RT_DEV f3 f3mk(float x, float y, float z) { return mk3<float>(x, y, z); }
+RT_DEV f3 normalize(f3 a) { const float k = __builtin_amdgcn_rsqf(len2(a)); return a * k; }
+RT_DEV f3 reflect(f3 v, f3 n) { const float a = dot(v, n) * 2.0f; return v - n * a; }                    // vec3.c:26
+RT_DEV f3 refract(f3 uv, f3 n, float eta) {                                                              // vec3.c:44-50
+    const float cos_theta = fminf(dot(-uv, n), 1.0f);
+    const f3 perp = (uv + n * cos_theta) * eta;
+    const float k = -__builtin_amdgcn_sqrtf(fabsf(1.0f - len2(perp)));
+    return perp + n * k;
+}
+// v_sin_f32 / v_cos_f32 take revolutions: sin(2*pi*x) for x in [0,1) is one instruction
+RT_DEV float sin2pi(float x) { return __builtin_amdgcn_sinf(x); }
+RT_DEV float cos2pi(float x) { return __builtin_amdgcn_cosf(x); }
+RT_DEV f3 uniform_ball(float a, float b, float c) {      // same law as vec3_random_in_unit_sphere (vec3.c:66-72)
+    const float z = 1.0f - 2.0f * a, s = __builtin_amdgcn_sqrtf(fmaxf(0.0f, 1.0f - z * z));
+    const float rad = cbrtf(c);
+    return f3mk(s * cos2pi(b), s * sin2pi(b), z) * rad;
+}
+RT_DEV f3 uniform_sphere(float a, float b) {             // same law as vec3_random_unit_vector_in_unit_sphere
+    const float z = 1.0f - 2.0f * a, s = __builtin_amdgcn_sqrtf(fmaxf(0.0f, 1.0f - z * z));
+    return f3mk(s * cos2pi(b), s * sin2pi(b), z);
+}
+
+struct Onb { f3 u, v, w; };
+RT_DEV Onb onb_from_w(f3 n) {                            // onb.c:7-12
+    Onb o; o.w = normalize(n);
+    const f3 a = fabsf(o.w.x) > 0.9f ? f3mk(0, 1, 0) : f3mk(1, 0, 0);
+    o.v = normalize(cross(o.w, a));
+    o.u = cross(o.w, o.v);
+    return o;
+}
+RT_DEV f3 onb_local(const Onb &o, f3 a) { return o.u * a.x + (o.v * a.y + o.w * a.z); }                 // onb.c:25-30
+
+// ---- textures (texture.c:115-166, perlin.c:33-50,108-148) ------------------------------------------
+RT_DEV float perlin_noise(const float *__restrict__ ranvec, const int *__restrict__ perm, f3 p) {
+    const float fx = floorf(p.x), fy = floorf(p.y), fz = floorf(p.z);
+    const float u = p.x - fx, v = p.y - fy, w = p.z - fz;
+    const int i = (int)fx, j = (int)fy, k = (int)fz;
+    const float uu = u * u * (3 - 2 * u), vv = v * v * (3 - 2 * v), ww = w * w * (3 - 2 * w);
+    float accum = 0.0f;
+#pragma unroll
+    for (int di = 0; di < 2; di++)
+#pragma unroll
+        for (int dj = 0; dj < 2; dj++)
+#pragma unroll
+            for (int dk = 0; dk < 2; dk++) {
+                const int h = perm[(i + di) & 255] ^ perm[256 + ((j + dj) & 255)] ^ perm[512 + ((k + dk) & 255)];
+                const f3 c = f3mk(ranvec[3 * h], ranvec[3 * h + 1], ranvec[3 * h + 2]);
+                const f3 wv = f3mk(u - di, v - dj, w - dk);
+                accum += (di * uu + (1 - di) * (1 - uu)) * (dj * vv + (1 - dj) * (1 - vv)) * (dk * ww + (1 - dk) * (1 - ww)) * dot(c, wv);
+            }
+    return accum;
+}
+RT_DEV float perlin_turb(const float *ranvec, const int *perm, f3 p) {
+    float accum = 0.0f, weight = 1.0f;
+    for (int i = 0; i < 7; i++) { accum += weight * perlin_noise(ranvec, perm, p); weight *= 0.5f; p = p * 2.0f; }
+    return fabsf(accum);
+}
+RT_DEV f3 texture_value(const SceneT<float> &sc, int tex, float u, float v, f3 p) {
+    TextureT<float> t = sc.textures[tex];
+    for (int guard = 0; guard < 8 && t.type == RTC_TEX_CHECKER; ++guard) {           // texture.c:121-124
+        const float sines = sinf(10 * p.x) * sinf(10 * p.y) * sinf(10 * p.z);
+        t = sc.textures[sines < 0 ? t.a : t.b];
+    }
+    if (t.type == RTC_TEX_SOLID) return f3mk(t.v[0], t.v[1], t.v[2]);
+    if (t.type == RTC_TEX_NOISE) {                                                    // texture.c:128-132
+        const float perl = perlin_turb(sc.perlin_vec + 768 * t.a, sc.perlin_perm + 768 * t.a, p);
+        const float val = 0.5f * (1.0f + sinf(t.v[0] * p.z + 10 * perl));
+        return f3mk(val, val, val);
+    }
+    if (t.type == RTC_TEX_IMAGE) {                                                    // texture.c:136-152, nearest texel, v flipped
+        const ImageDesc im = sc.images[t.a];
+        u = fminf(fmaxf(u, 0.0f), 1.0f); v = 1.0f - fminf(fmaxf(v, 0.0f), 1.0f);
+        int i = (int)(u * im.width), j = (int)(v * im.height);
+        if (i >= im.width) i = im.width - 1;
+        if (j >= im.height) j = im.height - 1;
+        const unsigned char *px = sc.image_data + im.offset + ((size_t)j * im.width + i) * 3;
+        const float s = 1.0f / 255.0f;
+        return f3mk(s * px[0], s * px[1], s * px[2]);
+    }
+    return f3mk(0, 0, 0);
+}
+RT_DEV bool material_needs_uv(const SceneT<float> &sc, const MaterialT<float> &m) {
+    if (m.tex < 0) return false;
+    const int ty = sc.textures[m.tex].type;
+    return ty == RTC_TEX_IMAGE || ty == RTC_TEX_CHECKER;   // a checker may select an image texture
+}
+
+// ---- light list pdf / sampling (hittable_list.c:165-180, hittable.c:760-864) -------------------------
+RT_DEV float light_pdf_one(const LightT<float> &l, f3 o, f3 v) {
+    if (l.kind == RTC_LIGHT_RECT) {                                                   // :772-788, tmin 1e-4
+        RayT<float> r; r.o = o; r.d = v; r.time = 0;
+        float t;
+        if (!rect_t<float>(l.d, l.axis, r, 0.0001f, Mth<float>::inf(), t)) return 0.0f;
+        const float vv = len2(v);
+        const float distance_squared = t * t * vv;
+        const float area = l.axis == RTC_AXIS_XZ ? (l.d[1] - l.d[0]) * (l.d[5] - l.d[4])
+                         : l.axis == RTC_AXIS_XY ? (l.d[1] - l.d[0]) * (l.d[3] - l.d[2]) : (l.d[3] - l.d[2]) * (l.d[5] - l.d[4]);
+        const float vn = l.axis == RTC_AXIS_XZ ? v.y : (l.axis == RTC_AXIS_XY ? v.z : v.x);
+        const float cosine = fabsf(vn) * __builtin_amdgcn_rsqf(vv);
+        return distance_squared * __builtin_amdgcn_rcpf(cosine * area);
+    }
+    if (l.kind == RTC_LIGHT_SPHERE) {                                                 // :760-768, tmin 1e-3
+        RayT<float> r; r.o = o; r.d = v; r.time = 0;
+        const f3 c = f3mk(l.d[0], l.d[1], l.d[2]);
+        float t;
+        if (!sphere_t<float>(c, l.d[3], r, 0.001f, Mth<float>::inf(), t)) return 0.0f;
+        const float cos_theta_max = __builtin_amdgcn_sqrtf(1.0f - l.d[3] * l.d[3] * __builtin_amdgcn_rcpf(len2(c - o)));
+        return __builtin_amdgcn_rcpf(2.0f * RT_PI * (1.0f - cos_theta_max));
+    }
+    return 0.0f;
+}
+RT_DEV float light_list_pdf(const SceneT<float> &sc, f3 o, f3 v) {
+    const float weight = 1.0f / (float)sc.n_lights;
+    float sum = 0.0f;
+    for (int i = 0; i < sc.n_lights; ++i) sum += weight * light_pdf_one(sc.lights[i], o, v);
+    return sum;
+}
+RT_DEV f3 light_random_one(const LightT<float> &l, f3 o, float r1, float r2) {
+    if (l.kind == RTC_LIGHT_RECT) {                                                   // :838-848
+        const float a0 = l.axis == RTC_AXIS_YZ ? l.d[2] : l.d[0], a1 = l.axis == RTC_AXIS_YZ ? l.d[3] : l.d[1];
+        const float b0 = l.axis == RTC_AXIS_XY ? l.d[2] : l.d[4], b1 = l.axis == RTC_AXIS_XY ? l.d[3] : l.d[5];
+        const float a = a0 + (a1 - a0) * r1, b = b0 + (b1 - b0) * r2;
+        const f3 p = l.axis == RTC_AXIS_XZ ? f3mk(a, l.d[6], b) : (l.axis == RTC_AXIS_XY ? f3mk(a, b, l.d[6]) : f3mk(l.d[6], a, b));
+        return p - o;
+    }
+    if (l.kind == RTC_LIGHT_SPHERE) {                                                 // :821-835
+        const f3 direction = f3mk(l.d[0], l.d[1], l.d[2]) - o;
+        const float distance_squared = len2(direction);
+        const Onb uvw = onb_from_w(direction);
+        const float z = 1.0f + r2 * (__builtin_amdgcn_sqrtf(1.0f - l.d[3] * l.d[3] * __builtin_amdgcn_rcpf(distance_squared)) - 1.0f);
+        const float s = __builtin_amdgcn_sqrtf(fmaxf(0.0f, 1.0f - z * z));
+        return onb_local(uvw, f3mk(cos2pi(r1) * s, sin2pi(r1) * s, z));
+    }
+    return f3mk(1, 0, 0);                                                             // :861-863
+}
+
+// ---- one bounce -----------------------------------------------------------------------------------
+struct PathState {
+    RayT<float> ray;
+    f3 T;        // throughput: product of the per-level weights of ray.c:80-83
+    f3 L;        // radiance collected by this sample
+};
+enum { RT_CONTINUE = 0, RT_TERMINATE = 1 };
+
+RT_DEV float schlick(float cosine, float ref_idx) {                                   // material.c:142
+    float r0 = (1.0f - ref_idx) * __builtin_amdgcn_rcpf(1.0f + ref_idx); r0 = r0 * r0;
+    const float m = 1.0f - cosine, m2 = m * m;
+    return r0 + (1.0f - r0) * (m2 * m2 * m);
+}
+RT_DEV f3 dielectric_dir(float ir, f3 dir, const RecT<float> &rec, float xi) {          // material.c:144-157
+    const float ratio = rec.front ? __builtin_amdgcn_rcpf(ir) : ir;
+    const f3 ud = normalize(dir);
+    const float cos_theta = fminf(dot(-ud, rec.n), 1.0f);
+    const float sin_theta = __builtin_amdgcn_sqrtf(fmaxf(0.0f, 1.0f - cos_theta * cos_theta));
+    if (ratio * sin_theta > 1.0f || schlick(cos_theta, ratio) > xi) return reflect(ud, rec.n);
+    return refract(ud, rec.n, ratio);
+}
+
+// Shade one hit.  integrator 0: ray.c:58-83 in loop form (L += T*emitted; T *= att*scattering_pdf/pdf_val).
+// integrator 1/2: 02 main.c:54-62 / 01 main.c:45-56 (T *= attenuation).  xi = this bounce's Philox block.
+RT_DEV int shade_hit(const SceneT<float> &sc, PathState &ps, const RecT<float> &rec, int integrator, float light_weight, const Rng4 &xi) {
+    const MaterialT<float> m = sc.materials[rec.mat];
+    const f3 d = ps.ray.d;
+    RayT<float> next; next.o = rec.p; next.time = ps.ray.time;
+    if (m.type == RTC_MAT_LIGHT) {                                                     // material.c:229-235 (03: front face only, F15)
+        if (integrator != 2 && (integrator == 1 || rec.front)) ps.L = ps.L + ps.T * texture_value(sc, m.tex, rec.u, rec.v, rec.p);
+        return RT_TERMINATE;                                                           // material_light_scatter returns 0
+    }
+    if (m.type == RTC_MAT_METAL) {                                                     // material.c:130-138 / 02 :132-141
+        const f3 reflected = reflect(normalize(d), rec.n);
+        next.d = m.param > 0.0f ? reflected + uniform_ball(xi.x, xi.y, xi.z) * m.param : reflected;
+        if (integrator != 0 && !(dot(next.d, rec.n) > 0.0f)) return RT_TERMINATE;      // 02/01: absorbed
+        ps.T = ps.T * f3mk(m.albedo[0], m.albedo[1], m.albedo[2]);
+        ps.ray = next; return RT_CONTINUE;
+    }
+    if (m.type == RTC_MAT_DIELECTRIC) {
+        next.d = dielectric_dir(m.param, d, rec, xi.x);
+        ps.ray = next; return RT_CONTINUE;                                             // attenuation (1,1,1)
+    }
+    if (m.type == RTC_MAT_ISOTROPIC) {                                                 // 02 material.c:173-177; 03's is UB (F14) -> absorb
+        if (integrator == 0) return RT_TERMINATE;
+        next.d = uniform_ball(xi.x, xi.y, xi.z);
+        ps.T = ps.T * texture_value(sc, m.tex, rec.u, rec.v, rec.p);
+        ps.ray = next; return RT_CONTINUE;
+    }
+    // lambertian
+    const f3 att = texture_value(sc, m.tex, rec.u, rec.v, rec.p);
+    if (integrator != 0) {                                                             // 02 material.c:120-128
+        f3 dir = rec.n + uniform_sphere(xi.x, xi.y);
+        if (fabsf(dir.x) < 1e-8f && fabsf(dir.y) < 1e-8f && fabsf(dir.z) < 1e-8f) dir = rec.n;
+        next.d = dir; ps.T = ps.T * att; ps.ray = next; return RT_CONTINUE;
+    }
+    // 03: mixture of the light-list pdf and the cosine pdf (ray.c:66-83, pdf.c:119-121,175-181)
+    const Onb uvw = onb_from_w(rec.n);
+    f3 dir;
+    if (sc.n_lights > 0 && xi.x < light_weight) {
+        int pick = (int)((float)sc.n_lights * xi.y);                                   // random_int(0,n-1), utils.h:26
+        pick = pick < sc.n_lights ? pick : sc.n_lights - 1;
+        dir = light_random_one(sc.lights[pick], rec.p, xi.z, xi.w);
+    } else {                                                                           // random_cosine_direction, vec3.c:97-107
+        const float r2 = xi.w, sr = __builtin_amdgcn_sqrtf(r2);
+        dir = onb_local(uvw, f3mk(cos2pi(xi.z) * sr, sin2pi(xi.z) * sr, __builtin_amdgcn_sqrtf(1.0f - r2)));
+    }
+    const f3 udir = normalize(dir);
+    const float cosw = dot(udir, uvw.w);
+    const float pdf_cos = cosw <= 0.0f ? 0.0f : cosw * RT_INV_PI;                       // pdf.c:100-103
+    const float pdf_light = sc.n_lights > 0 ? light_list_pdf(sc, rec.p, dir) : 0.0f;
+    const float pdf_val = light_weight * pdf_light + (1.0f - light_weight) * pdf_cos;   // pdf.c:119-121
+    const float cosn = dot(rec.n, udir);
+    const float spdf = cosn < 0.0f ? 0.0f : cosn * RT_INV_PI;                           // material.c:205-208
+    // spdf == 0: the reference keeps recursing but multiplies the child by 0; pdf_val == 0: 0/0 = NaN in the
+    // reference (scrubbed to a black sample).  Either way nothing more can reach the pixel.
+    if (!(spdf > 0.0f) || !(pdf_val > 0.0f)) return RT_TERMINATE;
+    ps.T = ps.T * (att * (spdf * __builtin_amdgcn_rcpf(pdf_val)));
+    next.d = dir; ps.ray = next;
+    return RT_CONTINUE;
+}
+
+RT_DEV f3 sky_color(f3 dir) {                                                          // 01 main.c:59-64
+    const float t = 0.5f * (normalize(dir).y + 1.0f);
+    return f3mk(1, 1, 1) * (1.0f - t) + f3mk(0.5f, 0.7f, 1.0f) * t;
+}

@@ -1,0 +1,290 @@
+// flatten.cpp -- pointer graph -> flat tables + linear BVH (product code, host C++).
+//
+// Replaces the reference's pointer-chasing scene (hittable_list.c:125-143 scanning hittable* -> void* -> struct,
+// bvh_node_hit hittable.c:485-490 recursing through malloc'd nodes) by arrays the GPU can index.
+// The reference's wrappers (translate/rotate/flip_face, hittable.c:527-591) become per-primitive "chains" of
+// ops kept in the reference's nesting order so the FP64 verify kernel can replay them op by op.
+#include "flatten.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <map>
+#include <unordered_map>
+
+namespace {
+
+struct Box { double lo[3], hi[3]; };
+static Box box_empty() { Box b; for (int a = 0; a < 3; a++) { b.lo[a] = HUGE_VAL; b.hi[a] = -HUGE_VAL; } return b; }
+static void box_grow(Box &b, const double p[3]) { for (int a = 0; a < 3; a++) { b.lo[a] = std::min(b.lo[a], p[a]); b.hi[a] = std::max(b.hi[a], p[a]); } }
+static void box_merge(Box &b, const Box &o) { box_grow(b, o.lo); box_grow(b, o.hi); }
+
+struct Flattener {
+    FlatScene &fs;
+    double time0, time1;
+    std::vector<OpT<double>> cur;                       // wrapper stack, outermost first
+    std::map<std::vector<double>, int> chain_ids;       // serialized ops -> chain id
+    std::unordered_map<const material *, int> mat_ids;
+    std::unordered_map<const texture *, int> tex_ids;
+    std::vector<Box> prim_boxes, bprim_boxes;
+    explicit Flattener(FlatScene &f, double t0, double t1) : fs(f), time0(t0), time1(t1) {
+        fs.chains.push_back(ChainRange{0, 0});
+        chain_ids[std::vector<double>()] = 0;
+    }
+
+    int chain_id() {
+        std::vector<double> key;
+        for (const auto &o : cur) { key.push_back(o.type); key.push_back(o.axis); key.push_back(o.a); key.push_back(o.b); key.push_back(o.c); }
+        auto it = chain_ids.find(key);
+        if (it != chain_ids.end()) return it->second;
+        int id = (int)fs.chains.size();
+        fs.chains.push_back(ChainRange{(int)fs.ops.size(), (int)cur.size()});
+        for (const auto &o : cur) fs.ops.push_back(o);
+        chain_ids[key] = id;
+        return id;
+    }
+    int texture_id(const texture *t) {
+        auto it = tex_ids.find(t);
+        if (it != tex_ids.end()) return it->second;
+        TextureT<double> d; std::memset(&d, 0, sizeof d);
+        d.type = (int)t->kind;
+        switch (t->kind) {
+        case RT_TEX_SOLID: d.v[0] = t->value.x; d.v[1] = t->value.y; d.v[2] = t->value.z; break;
+        case RT_TEX_CHECKER: d.a = texture_id(t->odd); d.b = texture_id(t->even); break;
+        case RT_TEX_NOISE:
+            d.a = (int)(fs.perlin_perm.size() / 768); d.v[0] = t->scale;
+            fs.perlin_vec.insert(fs.perlin_vec.end(), t->ranvec, t->ranvec + 768);
+            fs.perlin_perm.insert(fs.perlin_perm.end(), t->perm, t->perm + 768);
+            break;
+        case RT_TEX_IMAGE: {
+            d.a = (int)fs.images.size();
+            ImageDesc im; im.width = t->width; im.height = t->height; im.offset = (uint32_t)fs.image_data.size(); im.pad = 0;
+            fs.images.push_back(im);
+            fs.image_data.insert(fs.image_data.end(), t->pixels, t->pixels + (size_t)t->width * t->height * 3);
+            while (fs.image_data.size() % 16) fs.image_data.push_back(0);
+            break;
+        }
+        }
+        int id = (int)fs.textures.size();
+        fs.textures.push_back(d); tex_ids[t] = id;
+        return id;
+    }
+    int material_id(const material *m) {
+        auto it = mat_ids.find(m);
+        if (it != mat_ids.end()) return it->second;
+        MaterialT<double> d; std::memset(&d, 0, sizeof d);
+        d.type = (int)m->kind; d.tex = -1;
+        if (m->kind == RT_MAT_METAL) { d.albedo[0] = m->albedo.x; d.albedo[1] = m->albedo.y; d.albedo[2] = m->albedo.z; d.param = m->param; }
+        else if (m->kind == RT_MAT_DIELECTRIC) d.param = m->param;
+        else d.tex = texture_id(m->tex);
+        int id = (int)fs.materials.size();
+        fs.materials.push_back(d); mat_ids[m] = id;
+        return id;
+    }
+
+    // world-space bounds of a leaf given its object-space box: replay the wrapper stack inside-out
+    Box to_world(Box b) const {
+        for (int i = (int)cur.size() - 1; i >= 0; --i) {
+            const auto &o = cur[i];
+            if (o.type == RTC_OP_TRANSLATE) { double off[3] = {o.a, o.b, o.c}; for (int a = 0; a < 3; a++) { b.lo[a] += off[a]; b.hi[a] += off[a]; } }
+            else if (o.type == RTC_OP_ROTATE) {
+                Box r = box_empty();
+                for (int c = 0; c < 8; c++) {
+                    double p[3] = {(c & 1) ? b.hi[0] : b.lo[0], (c & 2) ? b.hi[1] : b.lo[1], (c & 4) ? b.hi[2] : b.lo[2]}, q[3] = {p[0], p[1], p[2]};
+                    const double s = o.a, cs = o.b;   // object -> parent uses (+sin, cos), hittable.c:554
+                    if (o.axis == RTC_ROT_X) { q[0] = cs * p[0] - s * p[1]; q[1] = s * p[0] + cs * p[1]; }
+                    else if (o.axis == RTC_ROT_Y) { q[0] = cs * p[0] + s * p[2]; q[2] = -s * p[0] + cs * p[2]; }
+                    else { q[1] = cs * p[1] - s * p[2]; q[2] = s * p[1] + cs * p[2]; }
+                    box_grow(r, q);
+                }
+                b = r;
+            }
+        }
+        return b;
+    }
+
+    bool leaf(const hittable *h, bool boundary) {
+        PrimT<double> p; std::memset(&p, 0, sizeof p);
+        Box b = box_empty();
+        if (h->kind == RT_H_SPHERE) {
+            p.type = RTC_PRIM_SPHERE; p.d[0] = h->c0.x; p.d[1] = h->c0.y; p.d[2] = h->c0.z; p.d[3] = h->r;
+            double r = std::fabs(h->r), lo[3] = {h->c0.x - r, h->c0.y - r, h->c0.z - r}, hi[3] = {h->c0.x + r, h->c0.y + r, h->c0.z + r};
+            box_grow(b, lo); box_grow(b, hi);
+        } else if (h->kind == RT_H_MOVING_SPHERE) {
+            p.type = RTC_PRIM_MSPHERE;
+            p.d[0] = h->c0.x; p.d[1] = h->c0.y; p.d[2] = h->c0.z; p.d[3] = h->c1.x; p.d[4] = h->c1.y; p.d[5] = h->c1.z;
+            p.d[6] = h->t0; p.d[7] = h->t1; p.d[8] = h->r;
+            double r = std::fabs(h->r);
+            for (double t : {time0, time1}) {
+                double k = (t - h->t0) / (h->t1 - h->t0);
+                double c[3] = {(h->c1.x - h->c0.x) * k + h->c0.x, (h->c1.y - h->c0.y) * k + h->c0.y, (h->c1.z - h->c0.z) * k + h->c0.z};
+                double lo[3] = {c[0] - r, c[1] - r, c[2] - r}, hi[3] = {c[0] + r, c[1] + r, c[2] + r};
+                box_grow(b, lo); box_grow(b, hi);
+            }
+        } else if (h->kind == RT_H_RECT) {
+            p.type = RTC_PRIM_RECT; p.axis = h->axis;
+            p.d[0] = h->lo.x; p.d[1] = h->hi.x; p.d[2] = h->lo.y; p.d[3] = h->hi.y; p.d[4] = h->lo.z; p.d[5] = h->hi.z; p.d[6] = h->k;
+            double lo[3] = {h->lo.x, h->lo.y, h->lo.z}, hi[3] = {h->hi.x, h->hi.y, h->hi.z};
+            int thin = h->axis == RTC_AXIS_XY ? 2 : (h->axis == RTC_AXIS_XZ ? 1 : 0);
+            lo[thin] = h->k - 0.0001; hi[thin] = h->k + 0.0001;
+            box_grow(b, lo); box_grow(b, hi);
+        } else return false;
+        p.mat = material_id(h->mat);
+        p.chain = chain_id();
+        (boundary ? fs.bprims : fs.prims).push_back(p);
+        (boundary ? bprim_boxes : prim_boxes).push_back(to_world(b));
+        if (!boundary) {
+            int depth = 0, flips = 0;
+            for (const auto &o : cur) { if (o.type == RTC_OP_FLIP) flips ^= 1; else depth++; }
+            fs.wrap_depth.push_back(depth); fs.flipped.push_back(flips);
+        }
+        return true;
+    }
+
+    bool walk(const hittable *h, bool boundary) {
+        switch (h->kind) {
+        case RT_H_SPHERE: case RT_H_MOVING_SPHERE: case RT_H_RECT: return leaf(h, boundary);
+        case RT_H_BOX: for (int i = 0; i < h->members->index; i++) if (!walk(h->members->objs[i], boundary)) return false; return true;
+        case RT_H_BVH: for (int i = 0; i < h->bvh_count; i++) if (!walk(h->members->objs[h->bvh_order[i]], boundary)) return false; return true;
+        case RT_H_TRANSLATE: case RT_H_ROTATE: case RT_H_FLIP: {
+            OpT<double> o; std::memset(&o, 0, sizeof o);
+            if (h->kind == RT_H_TRANSLATE) { o.type = RTC_OP_TRANSLATE; o.a = h->offset.x; o.b = h->offset.y; o.c = h->offset.z; }
+            else if (h->kind == RT_H_ROTATE) { o.type = RTC_OP_ROTATE; o.axis = h->axis; o.a = h->sin_theta; o.b = h->cos_theta; }
+            else o.type = RTC_OP_FLIP;
+            cur.push_back(o);
+            bool ok = walk(h->child, boundary);
+            cur.pop_back();
+            return ok;
+        }
+        case RT_H_MEDIUM: {
+            if (boundary) { fs.error = "constant_medium used as the boundary of another constant_medium is not supported"; return false; }
+            PrimT<double> p; std::memset(&p, 0, sizeof p);
+            p.type = RTC_PRIM_MEDIUM; p.d[0] = h->neg_inv_density; p.mat = material_id(h->mat); p.chain = chain_id();
+            p.bnd_first = (int)fs.bprims.size();
+            size_t first_box = bprim_boxes.size();
+            if (!walk(h->child, true)) return false;
+            p.bnd_count = (int)fs.bprims.size() - p.bnd_first;
+            Box b = box_empty();
+            for (size_t i = first_box; i < bprim_boxes.size(); i++) box_merge(b, bprim_boxes[i]);
+            fs.prims.push_back(p); prim_boxes.push_back(b);
+            int depth = 0, flips = 0;
+            for (const auto &o : cur) { if (o.type == RTC_OP_FLIP) flips ^= 1; else depth++; }
+            fs.wrap_depth.push_back(depth); fs.flipped.push_back(flips);
+            fs.n_media++;
+            return true;
+        }
+        }
+        fs.error = "unknown hittable kind"; return false;
+    }
+};
+
+// ---- binned-SAH BVH over world-space leaf boxes -------------------------------------------------
+struct Builder {
+    const std::vector<Box> &boxes;
+    std::vector<int> idx;
+    std::vector<BvhNode> &nodes;
+    std::vector<int> &leaf_prims;
+    static constexpr int kLeafMax = 4, kBins = 16;
+    struct Child { int child, count; Box box; };
+
+    static double area(const Box &b) { double d[3] = {b.hi[0] - b.lo[0], b.hi[1] - b.lo[1], b.hi[2] - b.lo[2]}; return 2.0 * (d[0] * d[1] + d[1] * d[2] + d[2] * d[0]); }
+    Box range_box(int lo, int hi) const { Box b = box_empty(); for (int i = lo; i < hi; i++) box_merge(b, boxes[idx[i]]); return b; }
+    static float down(double v) { float f = (float)v; if ((double)f > v) f = std::nextafterf(f, -HUGE_VALF); return f - std::fabs(f) * 1e-6f - 1e-6f; }
+    static float up(double v) { float f = (float)v; if ((double)f < v) f = std::nextafterf(f, HUGE_VALF); return f + std::fabs(f) * 1e-6f + 1e-6f; }
+
+    Child make_leaf(int lo, int hi, const Box &b) {
+        Child c; c.child = (int)leaf_prims.size(); c.count = hi - lo; c.box = b;
+        for (int i = lo; i < hi; i++) leaf_prims.push_back(idx[i]);
+        std::sort(leaf_prims.end() - (hi - lo), leaf_prims.end());
+        return c;
+    }
+    Child build(int lo, int hi) {
+        Box b = range_box(lo, hi);
+        int n = hi - lo;
+        if (n <= kLeafMax) return make_leaf(lo, hi, b);
+        // centroid bounds
+        Box cb = box_empty();
+        for (int i = lo; i < hi; i++) { const Box &x = boxes[idx[i]]; double c[3] = {0.5 * (x.lo[0] + x.hi[0]), 0.5 * (x.lo[1] + x.hi[1]), 0.5 * (x.lo[2] + x.hi[2])}; box_grow(cb, c); }
+        int best_axis = -1, best_bin = -1; double best_cost = HUGE_VAL;
+        for (int a = 0; a < 3; a++) {
+            double ext = cb.hi[a] - cb.lo[a];
+            if (!(ext > 0) || !std::isfinite(ext)) continue;
+            Box bins[kBins]; int cnt[kBins];
+            for (int k = 0; k < kBins; k++) { bins[k] = box_empty(); cnt[k] = 0; }
+            for (int i = lo; i < hi; i++) {
+                const Box &x = boxes[idx[i]];
+                int k = (int)(kBins * ((0.5 * (x.lo[a] + x.hi[a]) - cb.lo[a]) / ext)); k = std::min(std::max(k, 0), kBins - 1);
+                cnt[k]++; box_merge(bins[k], x);
+            }
+            double right_area[kBins]; int right_cnt[kBins];
+            Box acc = box_empty(); int c = 0;
+            for (int k = kBins - 1; k > 0; k--) { if (cnt[k]) box_merge(acc, bins[k]); c += cnt[k]; right_area[k] = c ? area(acc) : 0; right_cnt[k] = c; }
+            acc = box_empty(); c = 0;
+            for (int k = 0; k < kBins - 1; k++) {
+                if (cnt[k]) box_merge(acc, bins[k]); c += cnt[k];
+                if (c == 0 || right_cnt[k + 1] == 0) continue;
+                double cost = c * area(acc) + right_cnt[k + 1] * right_area[k + 1];
+                if (cost < best_cost) { best_cost = cost; best_axis = a; best_bin = k; }
+            }
+        }
+        int mid;
+        if (best_axis < 0) mid = lo + n / 2;   // all centroids coincide: split the range in the middle
+        else {
+            const int a = best_axis; const double ext = cb.hi[a] - cb.lo[a];
+            auto it = std::partition(idx.begin() + lo, idx.begin() + hi, [&](int p) {
+                const Box &x = boxes[p];
+                int k = (int)(kBins * ((0.5 * (x.lo[a] + x.hi[a]) - cb.lo[a]) / ext)); k = std::min(std::max(k, 0), kBins - 1);
+                return k <= best_bin;
+            });
+            mid = (int)(it - idx.begin());
+            if (mid == lo || mid == hi) mid = lo + n / 2;
+        }
+        int me = (int)nodes.size();
+        nodes.push_back(BvhNode());
+        Child l = build(lo, mid), r = build(mid, hi);
+        BvhNode &nd = nodes[me];
+        for (int a = 0; a < 3; a++) { nd.lo0[a] = down(l.box.lo[a]); nd.hi0[a] = up(l.box.hi[a]); nd.lo1[a] = down(r.box.lo[a]); nd.hi1[a] = up(r.box.hi[a]); }
+        nd.child0 = l.child; nd.count0 = l.count; nd.child1 = r.child; nd.count1 = r.count;
+        Child c; c.child = me; c.count = 0; c.box = b;
+        return c;
+    }
+};
+
+}  // namespace
+
+bool flatten_scene(const hittable_list *world, const hittable_list *lights, const color *background,
+                   double time0, double time1, int bvh_threshold, FlatScene &out) {
+    if (!world) { out.error = "world list is NULL"; return false; }
+    Flattener f(out, time0, time1);
+    for (int i = 0; i < world->index; i++)
+        if (!f.walk(world->objs[i], false)) { if (out.error.empty()) out.error = "unsupported hittable in world"; return false; }
+    if (background) { out.background[0] = background->x; out.background[1] = background->y; out.background[2] = background->z; }
+    // lights list: hittable_pdf_value / hittable_random (hittable.c:792-805,851-864) look through flip_face only;
+    // anything else contributes pdf 0 and the fixed direction (1,0,0).
+    if (lights)
+        for (int i = 0; i < lights->index; i++) {
+            const hittable *h = lights->objs[i];
+            while (h->kind == RT_H_FLIP) h = h->child;
+            LightT<double> l; std::memset(&l, 0, sizeof l);
+            if (h->kind == RT_H_SPHERE) { l.kind = RTC_LIGHT_SPHERE; l.d[0] = h->c0.x; l.d[1] = h->c0.y; l.d[2] = h->c0.z; l.d[3] = h->r; }
+            else if (h->kind == RT_H_RECT) {
+                l.kind = RTC_LIGHT_RECT; l.axis = h->axis;
+                l.d[0] = h->lo.x; l.d[1] = h->hi.x; l.d[2] = h->lo.y; l.d[3] = h->hi.y; l.d[4] = h->lo.z; l.d[5] = h->hi.z; l.d[6] = h->k;
+            } else l.kind = RTC_LIGHT_NONE;
+            out.lights.push_back(l);
+        }
+    if ((int)out.prims.size() > bvh_threshold) {
+        Builder b{f.prim_boxes, {}, out.nodes, out.leaf_prims};
+        b.idx.resize(out.prims.size());
+        for (size_t i = 0; i < b.idx.size(); i++) b.idx[i] = (int)i;
+        out.nodes.reserve(out.prims.size());
+        Builder::Child root = b.build(0, (int)b.idx.size());
+        if (root.count > 0) {   // degenerate: everything fell into one leaf -> wrap it in a node
+            BvhNode nd; std::memset(&nd, 0, sizeof nd);
+            for (int a = 0; a < 3; a++) { nd.lo0[a] = Builder::down(root.box.lo[a]); nd.hi0[a] = Builder::up(root.box.hi[a]); nd.lo1[a] = 1; nd.hi1[a] = -1; }
+            nd.child0 = root.child; nd.count0 = root.count; nd.child1 = 0; nd.count1 = 0;
+            out.nodes.clear(); out.nodes.push_back(nd);
+        }
+    }
+    return true;
+}

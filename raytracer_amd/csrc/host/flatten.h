@@ -1,0 +1,33 @@
+// flatten.h -- host flattener: pointer graph of include/raytracer.h -> flat tables of rtc_tables.h (product code).
+#pragma once
+#include <string>
+#include <vector>
+
+#include "../rtc_tables.h"
+#include "scene_internal.h"
+
+struct FlatScene {
+    std::vector<PrimT<double>> prims, bprims;
+    std::vector<OpT<double>> ops;
+    std::vector<ChainRange> chains;
+    std::vector<MaterialT<double>> materials;
+    std::vector<TextureT<double>> textures;
+    std::vector<LightT<double>> lights;
+    std::vector<double> perlin_vec;
+    std::vector<int> perlin_perm;
+    std::vector<ImageDesc> images;
+    std::vector<unsigned char> image_data;
+    std::vector<BvhNode> nodes;
+    std::vector<int> leaf_prims;
+    std::vector<int> wrap_depth;   // per prim: number of translate/rotate wrappers (for rtc_scene_dump_leaves)
+    std::vector<int> flipped;      // per prim: parity of flip_face wrappers
+    int n_media = 0;
+    double background[3] = {0, 0, 0};
+    std::string error;
+};
+
+// Walks world/lights once.  Primitive order = the reference's traversal order (list order, box sides in creation
+// order, BVH members in the order recorded by bvh_node_init).  Builds the BVH when the scene has more than
+// `bvh_threshold` leaves.  Returns false and sets out.error on unsupported graphs.
+bool flatten_scene(const hittable_list *world, const hittable_list *lights, const color *background,
+                   double time0, double time1, int bvh_threshold, FlatScene &out);

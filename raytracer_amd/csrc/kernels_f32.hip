@@ -1,0 +1,162 @@
+// kernels_f32.hip -- production path tracer for gfx950 (product code): persistent-thread megakernel + tonemap.
+//
+// Replaces the pixel/sample loop of 03_FullTracer/main.c:137-160 and the recursion of ray.c:50-84.
+//  * one wave64 = one 8x8 pixel tile; a lane owns one pixel for all samples of this call and keeps the pixel sum
+//    in registers, so the float4 accumulator in HBM is read and written once per call (8 x 128-byte rows per wave);
+//  * the recursion is a loop: every iteration traces ONE bounce for every live lane; a lane whose path ended
+//    regenerates its next sample in the same iteration, so the wave stays full until its tile runs out of samples;
+//  * the primitive loop index is wave-uniform: the scene tables of a small scene (Cornell: 13 leaves) are fetched
+//    with scalar loads into SGPRs -- no VGPRs, no vector memory traffic, nothing to miss in HBM;
+//  * material / pdf dispatch is a switch (rt_shade.hpp); random numbers are Philox4x32-10 on (pixel, sample, bounce).
+#include <hip/hip_runtime.h>
+
+#include "device/rt_shade.hpp"
+#include "kernels.h"
+
+namespace {
+
+// constant_medium_hit (hittable.c:563-584) for the flattened boundary range of a medium leaf.
+struct MediumF32 {
+    const SceneT<float> &sc; const RayT<float> &r; float tmin; uint32_t pixel, sample, bounce, k0, k1; int &draws;
+    struct Never { __device__ bool operator()(int, float, float &) const { return false; } };
+    __device__ bool operator()(int prim, float tmax, float &t_out) const {
+        const PrimT<float> &p = sc.prims[prim];
+        Never nv;
+        const float inf = Mth<float>::inf();
+        const HitT<float> a = closest_hit_range<float>(sc, sc.bprims, p.bnd_first, p.bnd_count, r, -inf, inf, nv);
+        if (a.prim < 0) return false;
+        const HitT<float> b = closest_hit_range<float>(sc, sc.bprims, p.bnd_first, p.bnd_count, r, a.t + 0.0001f, inf, nv);
+        if (b.prim < 0) return false;
+        float t1 = a.t, t2 = b.t;
+        if (t1 < tmin) t1 = tmin;
+        if (t2 > tmax) t2 = tmax;
+        if (t1 >= t2) return false;
+        if (t1 < 0) t1 = 0;
+        const RayT<float> rm = chain_enter(sc, p.chain, r);
+        const float ray_length = length(rm.d);
+        const float inside = (t2 - t1) * ray_length;
+        const int k = draws++;
+        const Rng4 blk = rng_block(pixel, sample, RT_TAG_MEDIA | (bounce << 8) | (uint32_t)(k >> 2), k0, k1);
+        const float xi = (k & 3) == 0 ? blk.x : ((k & 3) == 1 ? blk.y : ((k & 3) == 2 ? blk.z : blk.w));
+        const float hit_distance = p.d[0] * __logf(xi);
+        if (hit_distance > inside) return false;
+        t_out = t1 + hit_distance / ray_length;
+        return true;
+    }
+};
+
+constexpr int kStackCap = 32;
+
+template <bool BVH>
+__global__ void __launch_bounds__(256) k_pathtrace_mega(SceneT<float> sc, CameraT<float> cam, RenderParams P,
+                                                         float4 *__restrict__ accum, unsigned long long *__restrict__ ray_counter) {
+    __shared__ int lds_stack[BVH ? kStackCap * 256 : 1];
+    const int lane = threadIdx.x & 63;
+    int block = blockIdx.x;
+    if (BVH) {   // blocks with equal (id % 8) share an XCD and its L2: give each XCD one contiguous band of tiles
+        const int nb = gridDim.x, q = nb >> 3, r = nb & 7, xcd = block & 7;
+        block = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (block >> 3);
+    }
+    const int tile = block * 4 + (threadIdx.x >> 6);
+    if (tile >= P.n_tiles) return;   // wave-uniform
+    const int px = (tile % P.tiles_x) * 8 + (lane & 7), py = (tile / P.tiles_x) * 8 + (lane >> 3);
+    const bool valid = px < P.width && py < P.height;
+    const uint32_t pixel = (uint32_t)(py * P.width + px);
+    const float inv_w = 1.0f / (float)(P.width - 1), inv_h = 1.0f / (float)(P.height - 1);
+
+    f3 sum = f3mk(0, 0, 0);
+    unsigned nrays = 0;
+    int s_next = P.s_begin, depth = 0;
+    uint32_t s_cur = 0;
+    bool alive = false;
+    PathState ps;
+    ps.T = f3mk(1, 1, 1); ps.L = f3mk(0, 0, 0); ps.ray.o = f3mk(0, 0, 0); ps.ray.d = f3mk(0, 0, 1); ps.ray.time = 0;
+
+    for (;;) {
+        if (!alive && valid && s_next < P.s_end) {                         // main.c:150-152 + camera.c:46-53
+            s_cur = (uint32_t)s_next++;
+            const Rng4 c = rng_block(pixel, s_cur, RT_TAG_CAMERA, P.seed_lo, P.seed_hi);
+            const float u = ((float)px + c.x) * inv_w, v = ((float)py + c.y) * inv_h;
+            float dx = 0.0f, dy = 0.0f, tm = cam.time0;
+            if (cam.lens_radius > 0.0f) { const float rr = __builtin_amdgcn_sqrtf(c.z); dx = rr * cos2pi(c.w); dy = rr * sin2pi(c.w); }
+            if (P.use_time) tm = cam.time0 + (cam.time1 - cam.time0) * rng_block(pixel, s_cur, RT_TAG_TIME, P.seed_lo, P.seed_hi).x;
+            ps.ray = camera_ray<float>(cam, u, v, dx, dy, tm);
+            ps.T = f3mk(1, 1, 1); ps.L = f3mk(0, 0, 0);
+            depth = 0; alive = true;
+        }
+        if (__builtin_amdgcn_ballot_w64(alive) == 0) break;                // every lane of the wave is out of samples
+        if (alive) {
+            int draws = 0;
+            MediumF32 medium{sc, ps.ray, 0.001f, pixel, s_cur, (uint32_t)depth, P.seed_lo, P.seed_hi, draws};
+            HitT<float> h;
+            if (BVH) {
+                LdsStack stack(lds_stack + threadIdx.x, 256, kStackCap);
+                h = closest_hit_bvh<float>(sc, ps.ray, 0.001f, Mth<float>::inf(), stack, medium);   // ray.c:56
+            } else {
+                h = closest_hit_linear<float>(sc, ps.ray, 0.001f, Mth<float>::inf(), medium);
+            }
+            ++nrays;
+            int status;
+            if (h.prim < 0) {                                              // ray.c:56: background (01: sky gradient)
+                const f3 bg = P.integrator == 2 ? sky_color(ps.ray.d) : f3mk(sc.background[0], sc.background[1], sc.background[2]);
+                ps.L = ps.L + ps.T * bg;
+                status = RT_TERMINATE;
+            } else {
+                const PrimT<float> p = sc.prims[h.prim];
+                const MaterialT<float> &m = sc.materials[p.mat];
+                const RecT<float> rec = resolve_hit<float>(sc, ps.ray, p, h.t, material_needs_uv(sc, m));
+                const Rng4 xi = rng_block(pixel, s_cur, (uint32_t)depth, P.seed_lo, P.seed_hi);
+                status = shade_hit(sc, ps, rec, P.integrator, P.light_weight, xi);
+            }
+            ++depth;
+            if (status == RT_TERMINATE || depth >= P.max_depth) {          // ray.c:52: depth exhausted adds nothing
+                alive = false;
+                const bool finite = (fabsf(ps.L.x) < 3.0e38f) && (fabsf(ps.L.y) < 3.0e38f) && (fabsf(ps.L.z) < 3.0e38f);
+                if (finite) sum = sum + ps.L;                              // non-finite samples are dropped (reference: NaN pixel, F16)
+            }
+        }
+    }
+    if (valid) {
+        float4 a = accum[pixel];
+        a.x += sum.x; a.y += sum.y; a.z += sum.z; a.w += (float)(P.s_end - P.s_begin);
+        accum[pixel] = a;
+    }
+    // one atomic per wave for the ray counter
+    unsigned total = nrays;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) total += __shfl_xor(total, off, 64);
+    if (lane == 0) atomicAdd(ray_counter, (unsigned long long)total);
+}
+
+// write_color (ray.c:35-47): mean -> sqrt -> clamp [0, 0.999] -> *256 -> u8.  One lane per pixel.
+__global__ void __launch_bounds__(256) k_tonemap_u8(const float4 *__restrict__ accum, int n_pixels, unsigned char *__restrict__ rgb) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_pixels) return;
+    const float4 a = accum[i];
+    // double arithmetic like the reference (scale = 1.0/spp; sqrt(scale*c)): the byte must not depend on FP32 rounding
+    const double scale = a.w > 0.0f ? 1.0 / (double)a.w : 0.0;
+    const float c[3] = {a.x, a.y, a.z};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        double v = sqrt(scale * (double)c[k]);
+        v = (v < 0.0) ? 0.0 : ((v > 0.999) ? 0.999 : v);
+        if (!(v == v)) v = 0.0;                        // NaN -> 0 (the reference casts NaN to unsigned char: UB, F16)
+        rgb[3 * (size_t)i + k] = (unsigned char)(256 * v);
+    }
+}
+
+}  // namespace
+
+hipError_t launch_pathtrace_mega(const SceneT<float> &sc, const CameraT<float> &cam, const RenderParams &p,
+                                 float4 *accum, unsigned long long *ray_counter, hipStream_t stream) {
+    if (p.n_tiles <= 0 || p.s_end <= p.s_begin) return hipSuccess;
+    const unsigned blocks = (unsigned)((p.n_tiles + 3) / 4);
+    if (sc.n_nodes > 0) hipLaunchKernelGGL(k_pathtrace_mega<true>, dim3(blocks), dim3(256), 0, stream, sc, cam, p, accum, ray_counter);
+    else hipLaunchKernelGGL(k_pathtrace_mega<false>, dim3(blocks), dim3(256), 0, stream, sc, cam, p, accum, ray_counter);
+    return hipGetLastError();
+}
+hipError_t launch_tonemap_u8(const float4 *accum, int n_pixels, unsigned char *rgb, hipStream_t stream) {
+    if (n_pixels <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_tonemap_u8, dim3((unsigned)((n_pixels + 255) / 256)), dim3(256), 0, stream, accum, n_pixels, rgb);
+    return hipGetLastError();
+}

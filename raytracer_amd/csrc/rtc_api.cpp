@@ -1,0 +1,298 @@
+// rtc_api.cpp -- the C-ABI of include/rtc.h (product code; host side, compiled by hipcc).
+// Owns device memory for the flattened scene, launches the kernels of kernels_f64.hip / kernels_f32.hip.
+// There is deliberately no CPU path here: without a usable HIP device every compute entry point fails.
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "kernels.h"
+// hip_runtime.h declares a class template named `texture` (legacy texture references); the host API's opaque
+// `struct texture` (reference name, texture.h:20) is renamed inside this translation unit only.
+#define texture rtc_host_texture
+#include "host/flatten.h"
+#include "rtc.h"
+
+namespace {
+
+thread_local std::string g_error;
+int fail(int code, const std::string &msg) { g_error = msg; return code; }
+#define HIP_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return fail(RTC_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_)); } while (0)
+
+struct DevBuf {
+    void *p = nullptr; size_t bytes = 0;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    hipError_t upload(const void *src, size_t n) {
+        if (p) { (void)hipFree(p); p = nullptr; }
+        bytes = n;
+        if (n == 0) return hipSuccess;
+        hipError_t e = hipMalloc(&p, n);
+        if (e != hipSuccess) return e;
+        return hipMemcpy(p, src, n, hipMemcpyHostToDevice);
+    }
+};
+
+template <typename R> struct DeviceTables {
+    DevBuf prims, bprims, ops, chains, materials, textures, lights, perlin_vec, perlin_perm, images, image_data, nodes, leaf_prims;
+    SceneT<R> view;
+    bool ready = false;
+};
+
+template <typename R, typename Src> std::vector<R> convert_vec(const std::vector<Src> &s) { std::vector<R> d(s.size()); for (size_t i = 0; i < s.size(); i++) d[i] = (R)s[i]; return d; }
+template <typename R> PrimT<R> conv(const PrimT<double> &s) { PrimT<R> d; std::memset(&d, 0, sizeof d); d.type = s.type; d.axis = s.axis; d.mat = s.mat; d.chain = s.chain; d.bnd_first = s.bnd_first; d.bnd_count = s.bnd_count; for (int i = 0; i < 12; i++) d.d[i] = (R)s.d[i]; return d; }
+template <typename R> OpT<R> conv(const OpT<double> &s) { OpT<R> d; d.type = s.type; d.axis = s.axis; d.a = (R)s.a; d.b = (R)s.b; d.c = (R)s.c; return d; }
+template <typename R> MaterialT<R> conv(const MaterialT<double> &s) { MaterialT<R> d; d.type = s.type; d.tex = s.tex; for (int i = 0; i < 3; i++) d.albedo[i] = (R)s.albedo[i]; d.param = (R)s.param; return d; }
+template <typename R> TextureT<R> conv(const TextureT<double> &s) { TextureT<R> d; d.type = s.type; d.a = s.a; d.b = s.b; d.pad = 0; for (int i = 0; i < 4; i++) d.v[i] = (R)s.v[i]; return d; }
+template <typename R> LightT<R> conv(const LightT<double> &s) { LightT<R> d; d.kind = s.kind; d.axis = s.axis; d.pad0 = d.pad1 = 0; for (int i = 0; i < 8; i++) d.d[i] = (R)s.d[i]; return d; }
+
+template <typename R> hipError_t upload_tables(const FlatScene &fs, DeviceTables<R> &dt) {
+    hipError_t e;
+#define UP(buf, vec) do { e = dt.buf.upload((vec).data(), (vec).size() * sizeof((vec)[0])); if (e != hipSuccess) return e; } while (0)
+    std::vector<PrimT<R>> prims, bprims; for (const auto &x : fs.prims) prims.push_back(conv<R>(x)); for (const auto &x : fs.bprims) bprims.push_back(conv<R>(x));
+    std::vector<OpT<R>> ops; for (const auto &x : fs.ops) ops.push_back(conv<R>(x));
+    std::vector<MaterialT<R>> mats; for (const auto &x : fs.materials) mats.push_back(conv<R>(x));
+    std::vector<TextureT<R>> texs; for (const auto &x : fs.textures) texs.push_back(conv<R>(x));
+    std::vector<LightT<R>> lights; for (const auto &x : fs.lights) lights.push_back(conv<R>(x));
+    std::vector<R> pvec = convert_vec<R>(fs.perlin_vec);
+    UP(prims, prims); UP(bprims, bprims); UP(ops, ops); UP(chains, fs.chains); UP(materials, mats); UP(textures, texs); UP(lights, lights);
+    UP(perlin_vec, pvec); UP(perlin_perm, fs.perlin_perm); UP(images, fs.images); UP(image_data, fs.image_data); UP(nodes, fs.nodes); UP(leaf_prims, fs.leaf_prims);
+#undef UP
+    SceneT<R> &v = dt.view;
+    v.prims = (const PrimT<R> *)dt.prims.p; v.n_prims = (int)fs.prims.size();
+    v.bprims = (const PrimT<R> *)dt.bprims.p; v.n_bprims = (int)fs.bprims.size();
+    v.ops = (const OpT<R> *)dt.ops.p; v.chains = (const ChainRange *)dt.chains.p; v.n_chains = (int)fs.chains.size();
+    v.materials = (const MaterialT<R> *)dt.materials.p; v.n_materials = (int)fs.materials.size();
+    v.textures = (const TextureT<R> *)dt.textures.p; v.n_textures = (int)fs.textures.size();
+    v.lights = (const LightT<R> *)dt.lights.p; v.n_lights = (int)fs.lights.size();
+    v.perlin_vec = (const R *)dt.perlin_vec.p; v.perlin_perm = (const int *)dt.perlin_perm.p;
+    v.images = (const ImageDesc *)dt.images.p; v.image_data = (const unsigned char *)dt.image_data.p;
+    v.nodes = (const BvhNode *)dt.nodes.p; v.leaf_prims = (const int *)dt.leaf_prims.p; v.n_nodes = (int)fs.nodes.size();
+    v.n_media = fs.n_media;
+    for (int i = 0; i < 3; i++) v.background[i] = (R)fs.background[i];
+    dt.ready = true;
+    return hipSuccess;
+}
+
+template <typename R> CameraT<R> camera_tables(const camera *c) {
+    double f[24]; camera_fields(c, f);
+    CameraT<R> d;
+    R *dst[7] = {d.origin, d.llc, d.horizontal, d.vertical, d.u, d.v, d.w};
+    for (int i = 0; i < 7; i++) for (int k = 0; k < 3; k++) dst[i][k] = (R)f[3 * i + k];
+    d.lens_radius = (R)f[21]; d.time0 = (R)f[22]; d.time1 = (R)f[23];
+    return d;
+}
+
+struct StreamState { hipEvent_t ev0 = nullptr, ev1 = nullptr; uint64_t samples = 0; int launches = 0; bool pending = false; double total_ms = 0; };
+
+}  // namespace
+
+struct rtc_scene {
+    FlatScene flat;
+    int device = -1;
+    DeviceTables<float> f32;
+    DeviceTables<double> f64;
+    DevBuf ray_counter;
+    std::map<void *, StreamState> streams;
+    std::mutex mu;
+    ~rtc_scene() { for (auto &kv : streams) { if (kv.second.ev0) (void)hipEventDestroy(kv.second.ev0); if (kv.second.ev1) (void)hipEventDestroy(kv.second.ev1); } }
+};
+
+extern "C" {
+
+const char *rtc_last_error(void) { return g_error.c_str(); }
+
+int rtc_init(void) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) return fail(RTC_ERR_DEVICE, std::string("no HIP device: ") + (e != hipSuccess ? hipGetErrorString(e) : "device count is 0"));
+    int dev = 0; HIP_TRY(hipGetDevice(&dev));
+    hipDeviceProp_t prop; HIP_TRY(hipGetDeviceProperties(&prop, dev));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) return fail(RTC_ERR_DEVICE, std::string("kernels are built for gfx950, device is ") + prop.gcnArchName);
+    return RTC_OK;
+}
+const char *rtc_device_name(void) {
+    static thread_local char name[256];
+    int dev = 0; hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return "";
+    std::snprintf(name, sizeof name, "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
+    return name;
+}
+
+rtc_scene *rtc_scene_build(const hittable_list *world, const hittable_list *lights, const color *background, double time0, double time1) {
+    rtc_scene *s = new rtc_scene();
+    // brute force up to 64 leaves: the uniform loop runs out of SGPR-fed scalar loads; above that the linear BVH wins
+    if (!flatten_scene(world, lights, background, time0, time1, 64, s->flat)) { g_error = "flatten: " + s->flat.error; delete s; return nullptr; }
+    if (hipGetDevice(&s->device) != hipSuccess) { g_error = "rtc_scene_build: no current HIP device"; delete s; return nullptr; }
+    hipError_t e = upload_tables<float>(s->flat, s->f32);
+    unsigned long long zero = 0;
+    if (e == hipSuccess) e = s->ray_counter.upload(&zero, sizeof zero);
+    if (e != hipSuccess) { g_error = std::string("rtc_scene_build: upload failed: ") + hipGetErrorString(e); delete s; return nullptr; }
+    return s;
+}
+rtc_scene *rtc_scene_flatten_only(const hittable_list *world, const hittable_list *lights, const color *background, double time0, double time1) {
+    rtc_scene *s = new rtc_scene();
+    if (!flatten_scene(world, lights, background, time0, time1, 64, s->flat)) { g_error = "flatten: " + s->flat.error; delete s; return nullptr; }
+    return s;   // device == -1: every compute entry point refuses this handle
+}
+void rtc_scene_free(rtc_scene *scene) { delete scene; }
+int rtc_scene_num_prims(const rtc_scene *scene) { return scene ? (int)scene->flat.prims.size() : RTC_ERR_ARG; }
+
+int rtc_scene_dump_leaves(const rtc_scene *scene, double *out16, int cap) {
+    if (!scene || !out16) return fail(RTC_ERR_ARG, "rtc_scene_dump_leaves: null argument");
+    const FlatScene &fs = scene->flat;
+    static const int kind_of[4] = {1 /*HITTABLE_SPHERE*/, 2 /*MOVING_SPHERE*/, 3 /*RECT*/, 7 /*CONSTANT_MEDIUM*/};
+    int n = 0;
+    for (size_t i = 0; i < fs.prims.size(); i++, n++) {
+        if (n >= cap) continue;
+        const PrimT<double> &p = fs.prims[i];
+        double *d = out16 + 16 * (size_t)n; for (int k = 0; k < 16; k++) d[k] = 0;
+        d[0] = kind_of[p.type]; d[1] = fs.materials[p.mat].type;
+        if (p.type == RTC_PRIM_SPHERE) for (int k = 0; k < 4; k++) d[2 + k] = p.d[k];
+        else if (p.type == RTC_PRIM_MSPHERE) for (int k = 0; k < 9; k++) d[2 + k] = p.d[k];
+        else if (p.type == RTC_PRIM_RECT) { for (int k = 0; k < 7; k++) d[2 + k] = p.d[k]; d[9] = p.axis; }
+        else d[2] = p.d[0];
+        d[12] = fs.wrap_depth[i]; d[13] = fs.flipped[i];
+    }
+    return n;
+}
+
+static int ensure_f64(rtc_scene *s) {
+    if (s->device < 0) return fail(RTC_ERR_DEVICE, "scene was flattened on the host only (rtc_scene_flatten_only): no device tables");
+    if (s->f64.ready) return RTC_OK;
+    HIP_TRY(upload_tables<double>(s->flat, s->f64));
+    return RTC_OK;
+}
+
+int rtc_first_hit_f64(const rtc_scene *scene_c, const double *rays7, size_t n, double tmin, double tmax, int32_t *prim_id, double *t, double *rec12) {
+    rtc_scene *s = const_cast<rtc_scene *>(scene_c);
+    if (!s || (!rays7 && n) || !prim_id || !t) return fail(RTC_ERR_ARG, "rtc_first_hit_f64: null argument");
+    if (n == 0) return RTC_OK;
+    std::lock_guard<std::mutex> lk(s->mu);
+    int rc = ensure_f64(s); if (rc) return rc;
+    DevBuf d_rays, d_prim, d_t, d_rec;
+    HIP_TRY(d_rays.upload(rays7, n * 7 * sizeof(double)));
+    HIP_TRY(hipMalloc(&d_prim.p, n * sizeof(int32_t)));
+    HIP_TRY(hipMalloc(&d_t.p, n * sizeof(double)));
+    if (rec12) HIP_TRY(hipMalloc(&d_rec.p, n * 12 * sizeof(double)));
+    HIP_TRY(launch_first_hit_f64(s->f64.view, (const double *)d_rays.p, n, tmin, tmax, (int32_t *)d_prim.p, (double *)d_t.p, (double *)d_rec.p, nullptr));
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(prim_id, d_prim.p, n * sizeof(int32_t), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(t, d_t.p, n * sizeof(double), hipMemcpyDeviceToHost));
+    if (rec12) HIP_TRY(hipMemcpy(rec12, d_rec.p, n * 12 * sizeof(double), hipMemcpyDeviceToHost));
+    return RTC_OK;
+}
+
+int rtc_primary_first_hit_f64(const rtc_scene *scene_c, const camera *cam, const double *st2, const double *lens3, size_t n,
+                              double tmin, double tmax, int32_t *prim_id, double *t, double *rays7_out) {
+    rtc_scene *s = const_cast<rtc_scene *>(scene_c);
+    if (!s || !cam || (!st2 && n) || !prim_id || !t) return fail(RTC_ERR_ARG, "rtc_primary_first_hit_f64: null argument");
+    if (n == 0) return RTC_OK;
+    std::lock_guard<std::mutex> lk(s->mu);
+    int rc = ensure_f64(s); if (rc) return rc;
+    DevBuf d_st, d_lens, d_prim, d_t, d_rays;
+    HIP_TRY(d_st.upload(st2, n * 2 * sizeof(double)));
+    if (lens3) HIP_TRY(d_lens.upload(lens3, n * 3 * sizeof(double)));
+    HIP_TRY(hipMalloc(&d_prim.p, n * sizeof(int32_t)));
+    HIP_TRY(hipMalloc(&d_t.p, n * sizeof(double)));
+    if (rays7_out) HIP_TRY(hipMalloc(&d_rays.p, n * 7 * sizeof(double)));
+    HIP_TRY(launch_primary_first_hit_f64(s->f64.view, camera_tables<double>(cam), (const double *)d_st.p, (const double *)d_lens.p, n, tmin, tmax,
+                                         (int32_t *)d_prim.p, (double *)d_t.p, (double *)d_rays.p, nullptr));
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(prim_id, d_prim.p, n * sizeof(int32_t), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(t, d_t.p, n * sizeof(double), hipMemcpyDeviceToHost));
+    if (rays7_out) HIP_TRY(hipMemcpy(rays7_out, d_rays.p, n * 7 * sizeof(double), hipMemcpyDeviceToHost));
+    return RTC_OK;
+}
+
+static int check_settings(const rtc_settings *st) {
+    if (!st) return fail(RTC_ERR_ARG, "settings is NULL");
+    if (st->width < 2 || st->height < 2) return fail(RTC_ERR_ARG, "width and height must be >= 2 (the reference divides by W-1, H-1)");
+    if ((long long)st->width * st->height > (1ll << 30)) return fail(RTC_ERR_ARG, "image too large");
+    if (st->sample_end < st->sample_begin || st->sample_begin < 0) return fail(RTC_ERR_ARG, "bad sample range");
+    if (st->max_depth < 0 || st->max_depth > 4096) return fail(RTC_ERR_ARG, "bad max_depth");
+    if (st->integrator < 0 || st->integrator > 2) return fail(RTC_ERR_ARG, "integrator must be 0, 1 or 2");
+    if (st->kernel < 0 || st->kernel > 2) return fail(RTC_ERR_ARG, "kernel must be 0, 1 or 2");
+    return RTC_OK;
+}
+
+int rtc_render_device(const rtc_scene *scene_c, const camera *cam, const rtc_settings *st, float *accum_dev, void *stream_v) {
+    rtc_scene *s = const_cast<rtc_scene *>(scene_c);
+    if (!s || !cam || !accum_dev) return fail(RTC_ERR_ARG, "rtc_render_device: null argument");
+    if (s->device < 0) return fail(RTC_ERR_DEVICE, "scene was flattened on the host only (rtc_scene_flatten_only): no device tables");
+    int rc = check_settings(st); if (rc) return rc;
+    hipStream_t stream = (hipStream_t)stream_v;
+    std::lock_guard<std::mutex> lk(s->mu);
+    StreamState &ss = s->streams[stream_v];
+    if (!ss.ev0) { HIP_TRY(hipEventCreate(&ss.ev0)); HIP_TRY(hipEventCreate(&ss.ev1)); }
+    RenderParams p; std::memset(&p, 0, sizeof p);
+    p.width = st->width; p.height = st->height; p.s_begin = st->sample_begin; p.s_end = st->sample_end;
+    p.max_depth = st->max_depth; p.integrator = st->integrator;
+    p.seed_lo = (uint32_t)st->seed; p.seed_hi = (uint32_t)(st->seed >> 32);
+    p.light_weight = (float)st->mixture_light_weight;
+    p.tiles_x = (st->width + 7) / 8; p.tiles_y = (st->height + 7) / 8; p.n_tiles = p.tiles_x * p.tiles_y;
+    const CameraT<float> camf = camera_tables<float>(cam);
+    p.use_time = camf.time0 != camf.time1;
+    HIP_TRY(hipMemsetAsync(s->ray_counter.p, 0, sizeof(unsigned long long), stream));
+    HIP_TRY(hipEventRecord(ss.ev0, stream));
+    if (p.max_depth > 0) HIP_TRY(launch_pathtrace_mega(s->f32.view, camf, p, (float4 *)accum_dev, (unsigned long long *)s->ray_counter.p, stream));
+    HIP_TRY(hipEventRecord(ss.ev1, stream));
+    ss.samples = (uint64_t)st->width * st->height * (uint64_t)(st->sample_end - st->sample_begin);
+    ss.launches = 1; ss.pending = true;
+    return RTC_OK;
+}
+
+int rtc_render_stats(const rtc_scene *scene_c, void *stream_v, rtc_stats *out) {
+    rtc_scene *s = const_cast<rtc_scene *>(scene_c);
+    if (!s || !out) return fail(RTC_ERR_ARG, "rtc_render_stats: null argument");
+    std::lock_guard<std::mutex> lk(s->mu);
+    auto it = s->streams.find(stream_v);
+    if (it == s->streams.end() || !it->second.pending) return fail(RTC_ERR_ARG, "rtc_render_stats: no render was enqueued on this stream");
+    StreamState &ss = it->second;
+    HIP_TRY(hipEventSynchronize(ss.ev1));
+    float ms = 0; HIP_TRY(hipEventElapsedTime(&ms, ss.ev0, ss.ev1));
+    unsigned long long rays = 0;
+    HIP_TRY(hipMemcpy(&rays, s->ray_counter.p, sizeof rays, hipMemcpyDeviceToHost));
+    std::memset(out, 0, sizeof *out);
+    out->samples = ss.samples; out->rays = rays; out->kernel_ms = ms; out->total_ms = ss.total_ms > 0 ? ss.total_ms : ms;
+    out->kernel_launches = ss.launches; out->kernel_used = 1;
+    return RTC_OK;
+}
+
+int rtc_render(const rtc_scene *scene, const camera *cam, const rtc_settings *st, float *accum_host) {
+    if (!scene || !cam || !accum_host) return fail(RTC_ERR_ARG, "rtc_render: null argument");
+    int rc = check_settings(st); if (rc) return rc;
+    const auto t0 = std::chrono::steady_clock::now();
+    const size_t bytes = (size_t)st->width * st->height * 4 * sizeof(float);
+    DevBuf acc;
+    HIP_TRY(acc.upload(accum_host, bytes));
+    rc = rtc_render_device(scene, cam, st, (float *)acc.p, nullptr); if (rc) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(accum_host, acc.p, bytes, hipMemcpyDeviceToHost));
+    rtc_scene *s = const_cast<rtc_scene *>(scene);
+    s->streams[nullptr].total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return RTC_OK;
+}
+
+int rtc_tonemap_u8_device(const float *accum_dev, int width, int height, unsigned char *rgb_dev, void *stream) {
+    if (!accum_dev || !rgb_dev || width <= 0 || height <= 0) return fail(RTC_ERR_ARG, "rtc_tonemap_u8_device: bad argument");
+    HIP_TRY(launch_tonemap_u8((const float4 *)accum_dev, width * height, rgb_dev, (hipStream_t)stream));
+    return RTC_OK;
+}
+int rtc_tonemap_u8(const float *accum_host, int width, int height, unsigned char *rgb_host) {
+    if (!accum_host || !rgb_host || width <= 0 || height <= 0) return fail(RTC_ERR_ARG, "rtc_tonemap_u8: bad argument");
+    const size_t n = (size_t)width * height;
+    DevBuf acc, rgb;
+    HIP_TRY(acc.upload(accum_host, n * 4 * sizeof(float)));
+    HIP_TRY(hipMalloc(&rgb.p, n * 3));
+    int rc = rtc_tonemap_u8_device((const float *)acc.p, width, height, (unsigned char *)rgb.p, nullptr); if (rc) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(rgb_host, rgb.p, n * 3, hipMemcpyDeviceToHost));
+    return RTC_OK;
+}
+
+}  // extern "C"

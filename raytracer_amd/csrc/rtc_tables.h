@@ -1,0 +1,53 @@
+// rtc_tables.h -- flat scene tables shared by the host flattener and the HIP kernels (product code).
+//
+// One scene = a handful of linear arrays in HBM.  Records are small AoS structs because the two access patterns
+// that matter both want whole records: (1) the brute-force primitive loop indexes them with a wave-uniform index,
+// which hipcc turns into scalar loads (s_load_dwordx8/x16) that cost no VGPRs and no vector-memory issue slots;
+// (2) BVH traversal gathers one 64-byte node or one primitive per lane with dwordx4 vector loads.
+// Every table exists in an FP32 flavour (production path tracer) and an FP64 flavour (bit-exact first-hit check).
+#pragma once
+#include <stdint.h>
+
+enum { RTC_PRIM_SPHERE = 0, RTC_PRIM_MSPHERE = 1, RTC_PRIM_RECT = 2, RTC_PRIM_MEDIUM = 3 };
+enum { RTC_OP_TRANSLATE = 0, RTC_OP_ROTATE = 1, RTC_OP_FLIP = 2 };
+enum { RTC_MAT_LAMBERTIAN = 0, RTC_MAT_METAL = 1, RTC_MAT_DIELECTRIC = 2, RTC_MAT_LIGHT = 3, RTC_MAT_ISOTROPIC = 4 };
+enum { RTC_TEX_SOLID = 0, RTC_TEX_CHECKER = 1, RTC_TEX_NOISE = 2, RTC_TEX_IMAGE = 3 };
+enum { RTC_LIGHT_NONE = 0, RTC_LIGHT_SPHERE = 1, RTC_LIGHT_RECT = 2 };
+enum { RTC_AXIS_XY = 0, RTC_AXIS_XZ = 1, RTC_AXIS_YZ = 2 };   // rect_axis, hittable.h:69
+enum { RTC_ROT_X = 0, RTC_ROT_Y = 1, RTC_ROT_Z = 2 };         // rotation_axis, hittable.h:103
+
+// Leaf primitive in the reference's traversal (visit) order; its index is the primitive id.
+//   sphere : d = cx cy cz r
+//   msphere: d = c0(3) c1(3) time0 time1 r
+//   rect   : d = x0 x1 y0 y1 z0 z1 k          (axis = RTC_AXIS_*)
+//   medium : d = neg_inv_density              (bnd_first/bnd_count: boundary leaves in the bprims table)
+template <typename R> struct alignas(16) PrimT {
+    int type, axis, mat, chain;
+    int bnd_first, bnd_count, pad0, pad1;
+    R d[12];
+};
+// One wrapper of the reference's instance stack (translate / rotate / flip_face), outermost first.
+template <typename R> struct OpT { int type, axis; R a, b, c; };   // translate: offset xyz; rotate: a=sin b=cos
+struct ChainRange { int first, count; };                           // chain 0 is the empty chain
+template <typename R> struct MaterialT { int type, tex; R albedo[3]; R param; };   // metal: albedo+fuzz; dielectric: param=ir
+template <typename R> struct TextureT { int type, a, b, pad; R v[4]; };            // solid: v=rgb; checker: a=odd b=even; noise: a=perlin slot v[0]=scale; image: a=image slot
+template <typename R> struct LightT { int kind, axis, pad0, pad1; R d[8]; };       // entries of the `lights` list, flip_face unwrapped
+struct ImageDesc { int width, height; uint32_t offset, pad; };                     // RGB8 texels at image_data + offset
+// Two-child BVH node with both child boxes inline (one 64-byte fetch decides both children).
+// child >= 0: inner node index, count == 0;  count > 0: leaf, child = first slot in leaf_prims.
+struct alignas(16) BvhNode { float lo0[3]; int child0; float hi0[3]; int count0; float lo1[3]; int child1; float hi1[3]; int count1; };
+
+template <typename R> struct SceneT {
+    const PrimT<R> *prims;   int n_prims;
+    const PrimT<R> *bprims;  int n_bprims;
+    const OpT<R> *ops;       const ChainRange *chains; int n_chains;
+    const MaterialT<R> *materials; int n_materials;
+    const TextureT<R> *textures;   int n_textures;
+    const LightT<R> *lights; int n_lights;
+    const R *perlin_vec;     const int *perlin_perm;   // per noise slot: 768 reals, 768 ints
+    const ImageDesc *images; const unsigned char *image_data;
+    const BvhNode *nodes;    const int *leaf_prims; int n_nodes;   // n_nodes == 0: brute-force loop over prims
+    int n_media;             // media among prims (stochastic hits)
+    R background[3];
+};
+template <typename R> struct CameraT { R origin[3], llc[3], horizontal[3], vertical[3], u[3], v[3], w[3]; R lens_radius, time0, time1; };

@@ -592,6 +592,7 @@ int hittable_hit(hittable *o, ray *r, double tmin, double tmax, hit_record *rec)
         translate *b = o->obj; CNT(translate_calls);
         ray moved = {vsub(r->orig, b->offset), r->dir, r->time};
         if (!hittable_hit(b->obj, &moved, tmin, tmax, rec)) return 0;
+        CNT(translate_hits);
         rec->p = vadd(rec->p, b->offset);
         set_facenormal(rec, &moved, rec->normal);
         return 1;
@@ -603,6 +604,7 @@ int hittable_hit(hittable *o, ray *r, double tmin, double tmax, hit_record *rec)
         rotatePoint(r->dir, -ob->sin_theta, ob->cos_theta, ob->axis, &direction);
         ray rr = {origin, direction, r->time};
         if (!hittable_hit(ob->obj, &rr, tmin, tmax, rec)) return 0;
+        CNT(rotate_hits);
         vec3 p = rec->p, n = rec->normal;
         rotatePoint(rec->p, ob->sin_theta, ob->cos_theta, ob->axis, &p);
         rotatePoint(rec->normal, ob->sin_theta, ob->cos_theta, ob->axis, &n);
@@ -653,6 +655,7 @@ double hittable_pdf_value(hittable *o, point3 orig, vec3 v) {
         sphere *s = o->obj; hit_record rec; ray r = {orig, v, 0};
         CNT(light_pdf_sphere);
         if (!sphere_hit(s, &r, 0.001, HUGE_VAL, &rec)) return 0;
+        CNT(light_pdf_sphere_hits);
         double cos_theta_max = sqrt(1 - s->r * s->r / vlen2(vsub(s->center, orig)));
         double solid_angle = 2 * PI * (1 - cos_theta_max);
         return 1 / solid_angle;
@@ -660,6 +663,7 @@ double hittable_pdf_value(hittable *o, point3 orig, vec3 v) {
         rect *rc = o->obj; hit_record rec; ray r = {orig, v, 0};
         CNT(light_pdf_rect);
         if (!rect_hit(rc, &r, 0.0001, HUGE_VAL, &rec)) return 0;
+        CNT(light_pdf_rect_hits);
         double distance_squared = rec.t * rec.t * vlen2(v);
         double area = 0;
         if (rc->axis == XZ) area = (rc->x1 - rc->x0) * (rc->z1 - rc->z0);
@@ -874,6 +878,7 @@ int orc_render(hittable_list *world, hittable_list *lights, camera *cam, const o
                 double u = ((double)i + random_double()) / (double)(W - 1); /* main.c:150-151 */
                 double v = ((double)j + random_double()) / (double)(H - 1);
                 ray r = camera_get_ray(cam, u, v);
+                CNT(samples);
                 color c;
                 if (iterative) c = orc_ray_color_iter(&r, st, world, lights, &total_rays);
                 else c = orc_ray_color(&r, st, world, lights, st->max_depth);

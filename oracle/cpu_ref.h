@@ -239,6 +239,7 @@ typedef struct {
     uint64_t rect_tests, rect_hits, sphere_tests, sphere_hits, msphere_tests, aabb_tests, medium_tests;
     uint64_t translate_calls, rotate_calls, light_pdf_rect, light_pdf_sphere, light_sample_rect, light_sample_sphere;
     uint64_t cosine_sample, onb_builds, camera_rays, tex_noise, tex_checker, tex_image;
+    uint64_t translate_hits, rotate_hits, light_pdf_rect_hits, light_pdf_sphere_hits, samples;
 } orc_counters;
 void orc_counters_reset(void);
 void orc_counters_get(orc_counters *out);

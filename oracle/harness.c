@@ -395,6 +395,12 @@ static void dump_walk(hittable *o, int depth, int flipped, double *out, int *n, 
 int hx_dump_leaves(double *out16, int cap) { int n = 0; for (int i = 0; i < g_world->index; i++) dump_walk(g_world->objs[i], 0, 0, out16, &n, cap); return n; }
 
 #ifdef HX_ORACLE
+int hx_counters(int reset, unsigned long long *out, int cap) {
+    if (reset) { orc_counters_reset(); return 0; }
+    orc_counters c; orc_counters_get(&c);
+    int n = (int)(sizeof c / sizeof(unsigned long long)); if (n > cap) n = cap;
+    memcpy(out, &c, (size_t)n * sizeof(unsigned long long)); return n;
+}
 /* ---- oracle-only conveniences (scene state lives in this file) ---------------------------- */
 static orc_settings settings_from_view(int depth, int scrub) {
     orc_settings st; memset(&st, 0, sizeof st);

@@ -228,6 +228,23 @@ class Harness:
         return out, dict(samples=stats[0], rays=stats[1], seconds=stats[2])
 
 
+COUNTER_NAMES = """rays miss emit diffuse specular_metal specular_dielectric isotropic rect_tests rect_hits sphere_tests
+sphere_hits msphere_tests aabb_tests medium_tests translate_calls rotate_calls light_pdf_rect light_pdf_sphere
+light_sample_rect light_sample_sphere cosine_sample onb_builds camera_rays tex_noise tex_checker tex_image
+translate_hits rotate_hits light_pdf_rect_hits light_pdf_sphere_hits samples""".split()
+
+
+def counters_reset(h):
+    h.lib.hx_counters(C.c_int(1), None, C.c_int(0))
+
+
+def counters_get(h):
+    out = np.zeros(len(COUNTER_NAMES), dtype=np.uint64)
+    n = h.lib.hx_counters(C.c_int(0), out.ctypes.data_as(C.POINTER(C.c_ulonglong)), C.c_int(len(out)))
+    assert n == len(COUNTER_NAMES)
+    return dict(zip(COUNTER_NAMES, (int(x) for x in out)))
+
+
 def oracle():
     return Harness(ORACLE_SO)
 

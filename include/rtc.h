@@ -66,13 +66,16 @@ rtc_scene *rtc_scene_flatten_only(const hittable_list *world, const hittable_lis
 void rtc_scene_free(rtc_scene *scene);
 /* Number of flattened leaf primitives (visit order of the reference's traversal = primitive id). */
 int  rtc_scene_num_prims(const rtc_scene *scene);
-/* Flattened leaf table for tests: per leaf 16 doubles laid out like oracle/harness.c:hx_dump_leaves. */
+/* Flattened leaf table for inspection: per leaf 16 doubles = reference hittable_type (hittable.h:42-52), material type,
+ * geometry (sphere: c,r | moving sphere: c0,c1,t0,t1,r | rect: x0,x1,y0,y1,z0,z1,k,axis | medium: -1/density) from slot 2,
+ * slot 12 = number of translate/rotate wrappers, slot 13 = flip_face parity. */
 int  rtc_scene_dump_leaves(const rtc_scene *scene, double *out16, int cap);
 
 /* FP64, no-FMA closest hit for n host rays (7 doubles each: orig, dir, time): bit-exact replacement of
  * hittable_list_hit(world, r, tmin, tmax, &rec) (hittable_list.c:125-143).  prim_id[i] = -1 on miss.
  * Constant media are stochastic in the reference (hittable.c:574) and are skipped here.
- * rec12 (optional): hit, t, p(3), normal(3), u, v, front_face, material type -- layout of oracle/harness.c. */
+ * rec12 (optional): the hit_record of hittable.h:26-33 as 12 doubles: hit, t, p(3), normal(3), u, v, front_face,
+ * material type (-1 on miss). */
 int rtc_first_hit_f64(const rtc_scene *scene, const double *rays7, size_t n, double tmin, double tmax,
                       int32_t *prim_id, double *t, double *rec12);
 /* Same, but the rays are generated ON DEVICE from (s,t) screen coordinates exactly as camera_get_ray does

@@ -1,0 +1,132 @@
+"""CPU: the product's host half -- scene construction, flattening order, camera, PNG writer, C-ABI surface.
+
+No compute entry point is called here (there is no GPU in the build container and no CPU fallback in the product).
+"""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, ROOT, golden
+
+SCENES_VS_GOLDEN = {"simple": "simple", "cornell": "cornell", "final": "final02", "book1": "book1", "cornell02": "cornell02",
+                    "cornell_smoke": "cornell_smoke", "book2_random": "book2_random", "two_perlin": "two_perlin",
+                    "simple_light": "simple_light", "two_spheres": "two_spheres"}
+
+
+@pytest.mark.parametrize("scene", sorted(SCENES_VS_GOLDEN))
+def test_flattened_leaves_and_camera_match_the_reference(rtc, scene):
+    """Leaf order = the reference's traversal order (incl. its BVH quirk F8), geometry and rand() stream identical."""
+    fx = golden(f"first_hit_{SCENES_VS_GOLDEN[scene]}.npz")
+    sc, cam, view = rtc.build_named_scene(scene, host_only=True)
+    assert np.array_equal(sc.dump_leaves(), fx["leaves"])
+    assert np.array_equal(cam.fields(), fx["camera"])
+    assert sc.num_prims() == len(fx["leaves"])
+    sc.close()
+
+
+def test_camera_16x9(rtc):
+    fx = golden("first_hit_cornell_16x9.npz")
+    sc, cam, view = rtc.build_named_scene("cornell", aspect=16 / 9, host_only=True)
+    assert np.array_equal(cam.fields(), fx["camera"])
+
+
+def test_perlin_tables_follow_rand(rtc):
+    """texture_noise_init_scaled draws the reference's rand() sequence (perlin.c:67-75)."""
+    u = golden("unit_vectors.npz")
+    L = rtc.lib()
+
+    class Tex(C.Structure):  # prefix of struct texture in scene_internal.h
+        _fields_ = [("kind", C.c_int), ("value", C.c_double * 3), ("odd", C.c_void_p), ("even", C.c_void_p), ("scale", C.c_double),
+                    ("ranvec", C.POINTER(C.c_double)), ("perm", C.POINTER(C.c_int))]
+    L.srand(C.c_uint(3))
+    t = C.cast(L.texture_noise_init_scaled(5.0), C.POINTER(Tex)).contents
+    assert np.array_equal(np.ctypeslib.as_array(t.ranvec, (256, 3)), u["perlin_ranvec"])
+    assert np.array_equal(np.ctypeslib.as_array(t.perm, (3, 256)), u["perlin_perm"])
+
+
+def test_bvh_consumes_one_rand_per_reference_node(rtc):
+    """bvh_node_init must leave rand() where the reference's constructor leaves it (hittable.c:172)."""
+    L = rtc.lib()
+    libc = C.CDLL(None)
+    for n in (1, 2, 3, 7, 16, 100):
+        L.srand(C.c_uint(42))
+        lst = L.hittable_list_new_no_gc(n)
+        m = L.material_dielectric_new(1.5)
+        for i in range(n):
+            L.hittable_sphere_new(lst, rtc.api.v3((i, 0, 0)), 0.4, m)
+        L.bvh_node_init(None, lst, 0.0, 1.0)
+        after = libc.rand()
+        L.srand(C.c_uint(42))
+        nodes = lambda k: 1 if k <= 2 else 1 + nodes(k // 2) + nodes(k - k // 2)
+        for _ in range(nodes(n)):
+            libc.rand()
+        assert libc.rand() == after, n
+
+
+def test_list_grows_past_initial_size(rtc):
+    L = rtc.lib()
+    lst = L.hittable_list_new(4)
+    m = L.material_dielectric_new(1.5)
+    for i in range(5000):   # the reference's hittable_list_add has no bounds check (F17)
+        L.hittable_sphere_new(lst, rtc.api.v3((i, 0, 0)), 0.4, m)
+    assert L.hittable_list_index(lst) == 5000
+
+
+def test_texture_image_missing_file_returns_null(rtc, capfd):
+    L = rtc.lib()
+    L.texture_image_init.restype = C.c_void_p
+    assert L.texture_image_init(b"/nonexistent/earthmap.ppm") is None
+
+
+def test_png_roundtrip(rtc, tmp_path):
+    from PIL import Image
+    rng = np.random.default_rng(1)
+    img = rng.integers(0, 256, (37, 53, 3), dtype=np.uint8)
+    p = str(tmp_path / "a.png")
+    rtc.png_write(p, img, flip=True)      # stbi_flip_vertically_on_write(1), main.c:170
+    assert np.array_equal(np.asarray(Image.open(p)), img[::-1])
+    rtc.png_write(p, img, flip=False)
+    assert np.array_equal(np.asarray(Image.open(p)), img)
+
+
+def test_every_declared_symbol_is_exported(rtc):
+    """include/*.h vs librtc.so: every prototype in the headers resolves in the shared library."""
+    L = rtc.lib()
+    names = set()
+    for hdr in ("raytracer.h", "rtc.h"):
+        src = open(os.path.join(ROOT, "include", hdr)).read()
+        src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+        names |= set(re.findall(r"\b(\w+)\s*\([^;{]*\)\s*;", src))
+    names -= {"defined"}
+    assert len(names) > 55
+    missing = [n for n in sorted(names) if not hasattr(L, n)]
+    assert not missing, missing
+    assert set(rtc.api.HOST_SYMBOLS + rtc.api.RTC_SYMBOLS) <= names
+
+
+def test_compute_refuses_host_only_scene(rtc):
+    sc, cam, view = rtc.build_named_scene("cornell", host_only=True)
+    with pytest.raises(rtc.RtcError, match="host only"):
+        sc.first_hit(np.zeros((1, 7)))
+    acc = np.zeros((8, 8, 4), dtype=np.float32)
+    with pytest.raises(rtc.RtcError):
+        sc.render(cam, rtc.Settings(8, 8, 1), acc)
+
+
+def test_product_does_not_reference_the_oracle():
+    """The product tree must not import, link or name anything under oracle/."""
+    bad = []
+    for base in ("raytracer_amd", "include"):
+        for dp, _, fns in os.walk(os.path.join(ROOT, base)):
+            if os.sep + "build" in dp:
+                continue
+            for fn in fns:
+                if fn.endswith((".so", ".o", ".pyc")) or fn == "rtc_render":
+                    continue
+                txt = open(os.path.join(dp, fn), errors="ignore").read()
+                if re.search(r"cpu_ref|liboracle|hx_|orc_", txt) and fn != "scenes.c":
+                    bad.append(os.path.join(dp, fn))
+    assert not bad, bad

@@ -1,0 +1,176 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark: Msamples/s (whole job) on the 1080p Cornell box, N MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+A "step" is one whole frame of BASELINE.json configs[1] on every rank: the 03_FullTracer Cornell box (setupScene,
+main.c:34-63) at 1920x1080 with the camera aspect set to 16/9, depth 10, mixture weight 0.1, SPP_PER_GPU samples of
+every pixel per rank (256 = the reference's default, main.c:91).  The path shards by sample index: rank r renders the
+disjoint Philox sample range [r*spp, (r+1)*spp) of every pixel into its own float4 accumulator already resident in
+HBM (weak scaling: per-GPU work is fixed), then ONE RCCL reduce of the accumulators to rank 0 and the write_color pack
+on rank 0.  Everything inside the timed region runs through the C-ABI of include/rtc.h (librtc.so); torch only owns
+the device buffers, the streams and the process group.
+
+The JSON line also carries
+  roofline      FP32 VALU roofline of the path-tracing kernel: algorithmic FLOP/ray (tools/flop_model.py)
+                x rays per launch / HIP-event kernel time measured by the library on the launch stream;
+  cpu_baseline  the CPU oracle (a port pinned byte-for-byte to the compiled reference) on all host cores with a
+                per-thread counter RNG -- the "fair" CPU row -- on a bounded sample of the same workload, plus the
+                compiled reference itself on one thread (its rand() is a global lock: more threads are slower).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import raytracer_amd as ra  # noqa: E402
+from raytracer_amd import dist as rdist  # noqa: E402
+
+WIDTH, HEIGHT, DEPTH = 1920, 1080, 10
+SPP_PER_GPU = 256
+# tools/flop_model.py, Cornell 16:9 (DESIGN.md "Roofline"): minimal-algorithm FLOP per closest-hit query incl. shading
+ALGO_FLOP_PER_RAY = 218.6
+PEAK_FP32_VALU_TFLOPS = 157.3     # MI355X_MICROARCH.md: 256 CU x 4 SIMD x 32 lanes x 2 (FMA) x 2.4 GHz
+ALGO_HBM_BYTES_PER_PIXEL = 32     # float4 accumulator read + write once per launch
+
+
+def cpu_baseline(budget_s=15.0):
+    """Time the CPU side on this host (rank 0, N=1 only).  Imports the oracle: measurement only, never the product."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import hx
+    out = {}
+    o = hx.oracle()
+    o.set_stage(3)
+    o.build("cornell", aspect=16 / 9)
+    threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(os.cpu_count() or 1, 16)
+    _, st = o.oracle_render(WIDTH, HEIGHT, 0, 1, depth=DEPTH, rng="philox", seed=1, threads=threads)      # probe
+    rate = st["samples"] / max(st["seconds"], 1e-9)
+    spp = int(max(1, min(64, budget_s * rate / (WIDTH * HEIGHT))))
+    _, st = o.oracle_render(WIDTH, HEIGHT, 0, spp, depth=DEPTH, rng="philox", seed=2, threads=threads)
+    out["cpu_baseline"] = dict(value=st["samples"] / st["seconds"] / 1e6, unit="Msamples/s", cores=threads, kind="port",
+                               mrays_per_s=st["rays"] / st["seconds"] / 1e6, seconds=round(st["seconds"], 2),
+                               sample=f"Cornell 1920x1080 aspect 16/9, depth 10, {spp} spp = {int(st['samples'])} samples, "
+                                      f"oracle/cpu_ref.c, {threads} OpenMP threads, per-thread Philox (fair row)")
+    if os.path.exists(hx.REF03_SO):
+        r = hx.ref03()
+        r.build("cornell", aspect=16 / 9)
+        w, h, s = 480, 270, 6
+        t0 = time.perf_counter()
+        r.render_refloop(w, h, s, DEPTH, seed=1)
+        dt = time.perf_counter() - t0
+        rows = (h // 16) * 16                                 # main.c:132-133: floor(H/16) rows per chunk, 16 chunks
+        out["cpu_reference_1t"] = dict(value=w * rows * s / dt / 1e6, unit="Msamples/s", cores=1, kind="reference", seconds=round(dt, 2),
+                                       sample=f"compiled 03_FullTracer (oracle/_ref/libref03.so), its own loop main.c:132-160, "
+                                              f"{w}x{rows} px x {s} spp, 1 thread, rand()")
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--spp", type=int, default=SPP_PER_GPU, help="samples per pixel per GPU per step")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--png", default="", help="write the last frame here (rank 0)")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            sys.exit(f"--gpus {a.gpus} needs one process per GPU: launch with python -m torch.distributed.run --nproc-per-node {a.gpus}")
+        a.gpus = world
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    ra.rtc_init()                                                # raises without a gfx950 GPU: there is no CPU fallback
+
+    scene, cam, view = ra.build_named_scene("cornell", aspect=WIDTH / HEIGHT)
+    accum = rdist.new_accum(HEIGHT, WIDTH, dev)
+    rgb8 = torch.empty((HEIGHT, WIDTH, 3), dtype=torch.uint8, device=dev)
+    kernel_ms, rays_total = [], 0
+
+    def step(i, record):
+        nonlocal rays_total
+        begin, end = rdist.shard_samples(a.spp * world, rank, world, base=i * a.spp * world)
+        accum.zero_()
+        stream = rdist.render_into(scene, cam, ra.Settings(WIDTH, HEIGHT, 0, DEPTH, 0, seed=0, sample_begin=begin, sample_end=end), accum)
+        rdist.reduce_accum(accum, dst=0)                         # one collective per frame (RCCL over xGMI); no-op at N=1
+        if rank == 0:
+            rc = ra.lib().rtc_tonemap_u8_device(accum.data_ptr(), WIDTH, HEIGHT, rgb8.data_ptr(), stream)
+            assert rc == 0
+        if record:
+            st = scene.stats(stream)                             # waits for the render kernel's end event
+            kernel_ms.append(st["kernel_ms"])
+            rays_total += st["rays"]
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(a.warmup):
+        step(i, False)
+    fence()
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        step(a.warmup + i, True)
+    fence()
+    elapsed = time.perf_counter() - t0
+
+    t = torch.tensor([elapsed, float(rays_total), float(np.mean(kernel_ms)) if kernel_ms else 0.0], dtype=torch.float64, device=dev)
+    if world > 1:
+        tmax = t.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tsum = t.clone()
+        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        elapsed, rays_all, k_ms = tmax[0].item(), tsum[1].item(), tmax[2].item()
+    else:
+        rays_all, k_ms = t[1].item(), t[2].item()
+
+    if rank == 0:
+        samples_all = WIDTH * HEIGHT * a.spp * world * a.steps
+        rays_per_launch = rays_all / max(1, a.steps * world)
+        achieved = ALGO_FLOP_PER_RAY * rays_per_launch / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
+        line = {
+            "metric": "Msamples/sec (whole node) @1080p Cornell box", "value": samples_all / elapsed / 1e6, "unit": "Msamples/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed / max(1, a.steps) * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "03_FullTracer Cornell box (setupScene), mixture-PDF light/glass-sphere importance sampling, "
+                                   f"1920x1080, camera aspect 16/9, depth {DEPTH}, {a.spp} spp per GPU per step",
+                       "width": WIDTH, "height": HEIGHT, "spp_per_gpu": a.spp, "global_spp": a.spp * world, "max_depth": DEPTH,
+                       "sharding": f"samples/{world}", "collective": "reduce(sum) of float4[W*H] to rank 0" if world > 1 else "none"},
+            "mrays_per_s": rays_all / elapsed / 1e6, "rays_per_sample": rays_all / samples_all,
+            "roofline": {"bound": "valu", "achieved": achieved, "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_FP32_VALU_TFLOPS, "traffic": None,
+                         "kernel": "k_pathtrace_mega", "kernel_ms": k_ms, "rays_per_launch": rays_per_launch,
+                         "algorithmic_flop_per_ray": ALGO_FLOP_PER_RAY,
+                         "algorithmic_hbm_bytes_per_launch": ALGO_HBM_BYTES_PER_PIXEL * WIDTH * HEIGHT},
+        }
+        if world == 1 and not a.no_cpu:
+            line.update(cpu_baseline())
+            line["speedup_vs_cpu_baseline"] = line["value"] / line["cpu_baseline"]["value"]
+        if a.png:
+            ra.png_write(a.png, rgb8.cpu().numpy())
+        print(json.dumps(line), flush=True)
+    scene.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -73,7 +73,9 @@ int  rtc_scene_dump_leaves(const rtc_scene *scene, double *out16, int cap);
 
 /* FP64, no-FMA closest hit for n host rays (7 doubles each: orig, dir, time): bit-exact replacement of
  * hittable_list_hit(world, r, tmin, tmax, &rec) (hittable_list.c:125-143).  prim_id[i] = -1 on miss.
- * Constant media are stochastic in the reference (hittable.c:574) and are skipped here.
+ * The kernel replays the reference's own traversal (list order; bvh_node_hit's left-then-right recursion over the tree
+ * bvh_node_constructor builds, culled by the float-reciprocal aabb_hit of aabb.c:33-63), so even leaves that share a t
+ * resolve to the leaf the reference keeps.  Constant media are stochastic in the reference (hittable.c:574) and are skipped.
  * rec12 (optional): the hit_record of hittable.h:26-33 as 12 doubles: hit, t, p(3), normal(3), u, v, front_face,
  * material type (-1 on miss). */
 int rtc_first_hit_f64(const rtc_scene *scene, const double *rays7, size_t n, double tmin, double tmax,
@@ -83,6 +85,13 @@ int rtc_first_hit_f64(const rtc_scene *scene, const double *rays7, size_t n, dou
  * (NULL = no lens offset, time 0).  rays7_out (optional) returns the generated rays. */
 int rtc_primary_first_hit_f64(const rtc_scene *scene, const camera *cam, const double *st2, const double *lens3,
                               size_t n, double tmin, double tmax, int32_t *prim_id, double *t, double *rays7_out);
+
+/* The PRODUCTION traversal on its own: hittable_list_hit (hittable_list.c:125-143) as the FP32 path tracer executes it
+ * (brute-force leaf loop up to 64 leaves, flattened SoA BVH with a per-lane LDS stack above), rays converted to float.
+ * Ties between leaves go to the highest primitive id; media are skipped.  Agreement with rtc_first_hit_f64 is a
+ * tolerance statement (tests/test_gpu_first_hit.py), not a bit-exact one. */
+int rtc_first_hit_f32(const rtc_scene *scene, const double *rays7, size_t n, double tmin, double tmax,
+                      int32_t *prim_id, float *t);
 
 /* The hot path: replaces the pixel/sample loop of 03 main.c:137-160 (camera_get_ray + ray_color + sum).
  * accum_rgba is W*H float4 = (sum R, sum G, sum B, sample count), row j=0 at the BOTTOM like the reference's
@@ -96,7 +105,8 @@ int rtc_render(const rtc_scene *scene, const camera *cam, const rtc_settings *se
 int rtc_render_stats(const rtc_scene *scene, void *stream, rtc_stats *out);
 
 /* write_color (ray.c:35-47): rgb/count -> sqrt -> clamp [0,0.999] -> *256 -> u8, for every pixel, on device.
- * rgb_u8 is W*H*3, same row order as accum (flip at PNG time like main.c:170). Non-finite sums map to 0. */
+ * rgb_u8 is W*H*3, same row order as accum (flip at PNG time like main.c:170).  NaN and negative sums map to 0
+ * (the reference casts NaN to unsigned char: undefined, F16); +inf clamps to 255 like any large value. */
 int rtc_tonemap_u8_device(const float *accum_rgba_device, int width, int height, unsigned char *rgb_u8_device, void *stream);
 int rtc_tonemap_u8(const float *accum_rgba_host, int width, int height, unsigned char *rgb_u8_host);
 

@@ -824,7 +824,10 @@ color orc_ray_color_iter(ray *r0, const orc_settings *st, hittable_list *world, 
             scatter_record srec;
             color emitted = material_emitted(rec.mat, &rec, rec.u, rec.v, rec.p);
             if (material_scatter(rec.mat, &r, &rec, &srec) == 0) { CNT(emit); L = vadd(L, vmul(T, emitted)); break; }
-            if (srec.is_specular) { T = vmul(T, srec.attenuation); r = srec.specular_ray; continue; }
+            if (srec.is_specular) {
+                if (rec.mat->type == MATERIAL_METAL) CNT(specular_metal); else CNT(specular_dielectric);
+                T = vmul(T, srec.attenuation); r = srec.specular_ray; continue;
+            }
             CNT(diffuse);
             L = vadd(L, vmul(T, emitted));
             pdf light_pdf; pdf_hittable_list li; pdf_hittable_list_init_stack(&light_pdf, &li, lights, rec.p);

@@ -108,18 +108,26 @@ int hx_camera_rays(int n, const double *uv, double *rays7) {
 }
 
 /* ---- leaf walker: primitive ids in the reference's visit order ----------------------------- */
-typedef struct { double t; void *mat; int next_id; int found; double tmin; } leaf_probe;
+/* A leaf is "the" hit leaf when its own single-leaf record has the authoritative t and material.  Where several
+ * leaves qualify (coplanar rects of neighbouring boxes share a t), u,v -- which no wrapper rewrites -- tell which one
+ * the reference's traversal really kept: its float-reciprocal aabb_hit (F9) may have culled the later candidate.
+ * found = last leaf matching t, material, u and v; found_loose = last leaf matching t and material only (used when
+ * u,v are NaN, F20). */
+typedef struct { double t; void *mat; int next_id; int found; double tmin; double u, v; int found_loose; } leaf_probe;
 static void walk(hittable *o, ray r, leaf_probe *pr) {
     switch (o->t) {
     case HITTABLE_SPHERE: case HITTABLE_MOVING_SPHERE: case HITTABLE_RECT: {
         int id = pr->next_id++;
         hit_record rec;
-        if (pr->mat && hittable_hit(o, &r, pr->tmin, HUGE_VAL, &rec) && rec.t == pr->t && (void *)rec.mat == pr->mat) pr->found = id;
+        if (pr->mat && hittable_hit(o, &r, pr->tmin, HUGE_VAL, &rec) && rec.t == pr->t && (void *)rec.mat == pr->mat) {
+            pr->found_loose = id;
+            if (rec.u == pr->u && rec.v == pr->v) pr->found = id;
+        }
         break;
     }
     case HITTABLE_CONSTANT_MEDIUM: { /* stochastic: identified by its private phase-function material */
         int id = pr->next_id++;
-        if (pr->mat && (void *)((constant_medium *)o->obj)->phase_function == pr->mat) pr->found = id;
+        if (pr->mat && (void *)((constant_medium *)o->obj)->phase_function == pr->mat) pr->found = pr->found_loose = id;
         break;
     }
     case HITTABLE_BOX: { hittable_list *l = (hittable_list *)((box *)o->obj)->sides; for (int i = 0; i < l->index; i++) walk(l->objs[i], r, pr); break; }
@@ -138,7 +146,7 @@ static void walk(hittable *o, ray r, leaf_probe *pr) {
     }
 }
 int hx_num_leaves(void) {
-    leaf_probe pr = {0, NULL, 0, -1, 0}; ray r; memset(&r, 0, sizeof r); r.dir.x = 1;
+    leaf_probe pr = {0, NULL, 0, -1, 0, 0, 0, -1}; ray r; memset(&r, 0, sizeof r); r.dir.x = 1;
     for (int i = 0; i < g_world->index; i++) walk(g_world->objs[i], r, &pr);
     return pr.next_id;
 }
@@ -150,9 +158,9 @@ int hx_hit_rays(int n, const double *rays7, double tmin, double tmax, double *re
         if (prim) {
             prim[i] = -1;
             if (hit) {
-                leaf_probe pr = {rec.t, (void *)rec.mat, 0, -1, tmin};
+                leaf_probe pr = {rec.t, (void *)rec.mat, 0, -1, tmin, rec.u, rec.v, -1};
                 for (int k = 0; k < g_world->index; k++) walk(g_world->objs[k], r, &pr);
-                prim[i] = pr.found >= 0 ? pr.found : -2; /* -2: walker found no leaf with that t (must not happen) */
+                prim[i] = pr.found >= 0 ? pr.found : (pr.found_loose >= 0 ? pr.found_loose : -2); /* -2: walker found no leaf with that t (must not happen) */
             }
         }
     }

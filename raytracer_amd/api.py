@@ -62,7 +62,7 @@ hittable_rect_new hittable_box_new hittable_moving_sphere_new bvh_node_init hitt
 hittable_rotate_init hittable_constant_medium_init hittable_constant_medium_init_c hittable_flip_face_init
 hittable_free camera_new camera_free camera_fields rt_scene_build rt_write_png rt_write_ppm_p3""".split()
 RTC_SYMBOLS = """rtc_init rtc_last_error rtc_device_name rtc_scene_build rtc_scene_flatten_only rtc_scene_free rtc_scene_num_prims
-rtc_scene_dump_leaves rtc_first_hit_f64 rtc_primary_first_hit_f64 rtc_render_device rtc_render rtc_render_stats
+rtc_scene_dump_leaves rtc_first_hit_f64 rtc_first_hit_f32 rtc_primary_first_hit_f64 rtc_render_device rtc_render rtc_render_stats
 rtc_tonemap_u8_device rtc_tonemap_u8""".split()
 
 
@@ -121,6 +121,7 @@ def lib():
     L.rtc_scene_num_prims.argtypes = [_P]
     L.rtc_scene_dump_leaves.argtypes = [_P, _dp, C.c_int]
     L.rtc_first_hit_f64.argtypes = [_P, _dp, C.c_size_t, C.c_double, C.c_double, _P, _dp, _dp]
+    L.rtc_first_hit_f32.argtypes = [_P, _dp, C.c_size_t, C.c_double, C.c_double, _P, _P]
     L.rtc_primary_first_hit_f64.argtypes = [_P, _P, _dp, _dp, C.c_size_t, C.c_double, C.c_double, _P, _dp, _dp]
     L.rtc_render_device.argtypes = [_P, _P, C.POINTER(RtcSettings), _P, _P]
     L.rtc_render.argtypes = [_P, _P, C.POINTER(RtcSettings), _P]
@@ -201,6 +202,15 @@ class Scene:
         _check(lib().rtc_first_hit_f64(self.handle, rays7.ctypes.data_as(_dp), n, tmin, tmax, prim.ctypes.data, t.ctypes.data_as(_dp),
                                        rec.ctypes.data_as(_dp) if want_rec else None), "rtc_first_hit_f64")
         return (prim, t, rec) if want_rec else (prim, t)
+
+    def first_hit_f32(self, rays7, tmin=0.001, tmax=np.inf):
+        """The production FP32 traversal alone: (prim int32, t float32)."""
+        rays7 = np.ascontiguousarray(rays7, dtype=np.float64)
+        n = rays7.size // 7
+        prim = np.zeros(n, dtype=np.int32)
+        t = np.zeros(n, dtype=np.float32)
+        _check(lib().rtc_first_hit_f32(self.handle, rays7.ctypes.data_as(_dp), n, tmin, tmax, prim.ctypes.data, t.ctypes.data), "rtc_first_hit_f32")
+        return prim, t
 
     def primary_first_hit(self, cam, st2, lens3=None, tmin=0.001, tmax=np.inf):
         st2 = np.ascontiguousarray(st2, dtype=np.float64)

@@ -74,6 +74,23 @@ template <typename R> RT_DEV bool sphere_t(V3<R> center, R rad, const RayT<R> &r
     if (t < tmin || t > tmax) { t = Mth<R>::div(-half_b + sq, a); if (t < tmin || t > tmax) return false; }
     t_out = t; return true;
 }
+// FP32 production form of the same test.  The textbook discriminant half_b^2 - a*c cancels catastrophically in float
+// once the radius is large against the feature size (ground sphere r = 1000, fog boundary r = 5000: c = |oc|^2 - r^2
+// carries an absolute error of ~r^2 * 2^-23).  Same roots, evaluated from the point of closest approach instead
+// (Haines et al., "Precision improvements for ray/sphere intersection", Ray Tracing Gems 2019, ch. 7):
+//   tc = -half_b/a,  l = oc + tc*d (perpendicular offset),  roots = tc -+ sqrt((r^2 - |l|^2)/a).
+template <> RT_DEV bool sphere_t<float>(V3<float> center, float rad, const RayT<float> &r, float tmin, float tmax, float &t_out) {
+    const V3<float> oc = r.o - center;
+    const float inv_a = __builtin_amdgcn_rcpf(len2(r.d));
+    const float tc = -dot(oc, r.d) * inv_a;
+    const V3<float> l = oc + r.d * tc;
+    const float q = (rad * rad - len2(l)) * inv_a;
+    if (q < 0.0f) return false;
+    const float sq = __builtin_amdgcn_sqrtf(q);
+    float t = tc - sq;
+    if (t < tmin || t > tmax) { t = tc + sq; if (t < tmin || t > tmax) return false; }
+    t_out = t; return true;
+}
 template <typename R> RT_DEV V3<R> msphere_center(const R *d, R time) {  // moving_sphere_center :455-458
     const R k = Mth<R>::div(time - d[6], d[7] - d[6]);
     return mk3<R>((d[3] - d[0]) * k + d[0], (d[4] - d[1]) * k + d[1], (d[5] - d[2]) * k + d[2]);
@@ -90,10 +107,26 @@ template <typename R> RT_DEV bool rect_t(const R *d, int axis, const RayT<R> &r,
     else { if (z < d[4] || z > d[5] || y < d[2] || y > d[3]) return false; }
     t_out = t; return true;
 }
-template <typename R> RT_DEV bool leaf_t(const PrimT<R> &p, const RayT<R> &rl, R tmin, R tmax, R &t) {
-    if (p.type == RTC_PRIM_RECT) return rect_t(p.d, p.axis, rl, tmin, tmax, t);
-    if (p.type == RTC_PRIM_SPHERE) return sphere_t(mk3<R>(p.d[0], p.d[1], p.d[2]), p.d[3], rl, tmin, tmax, t);
-    if (p.type == RTC_PRIM_MSPHERE) return sphere_t(msphere_center(p.d, rl.time), p.d[8], rl, tmin, tmax, t);
+// A ray that STARTS on a sphere (the path tracer's scattered rays): in exact arithmetic the roots are {0, -2*half_b/a};
+// tmin rejects the first, so only the far one can be a hit.  In FP32 the "0" root comes out as +-1e-4/cos(theta) for
+// r = 1000 -- often past tmin = 0.001 -- and the ray would hit the surface it is leaving.  The FP64 check path never
+// passes from_here: the reference's doubles keep that root ~1e-13 and its tmin test does the job.
+template <typename R> RT_DEV bool sphere_leave_t(V3<R> center, const RayT<R> &r, R tmin, R tmax, R &t_out) {
+    const V3<R> oc = r.o - center;
+    const R t = (R)-2 * Mth<R>::div(dot(oc, r.d), len2(r.d));
+    if (t < tmin || t > tmax) return false;
+    t_out = t; return true;
+}
+template <typename R> RT_DEV bool leaf_t(const PrimT<R> &p, const RayT<R> &rl, R tmin, R tmax, R &t, bool from_here = false) {
+    if (p.type == RTC_PRIM_RECT) return !from_here && rect_t(p.d, p.axis, rl, tmin, tmax, t);   // a ray cannot re-hit the plane it leaves
+    if (p.type == RTC_PRIM_SPHERE) {
+        const V3<R> c = mk3<R>(p.d[0], p.d[1], p.d[2]);
+        return from_here ? sphere_leave_t(c, rl, tmin, tmax, t) : sphere_t(c, p.d[3], rl, tmin, tmax, t);
+    }
+    if (p.type == RTC_PRIM_MSPHERE) {
+        const V3<R> c = msphere_center(p.d, rl.time);
+        return from_here ? sphere_leave_t(c, rl, tmin, tmax, t) : sphere_t(c, p.d[8], rl, tmin, tmax, t);
+    }
     return false;
 }
 
@@ -103,7 +136,7 @@ template <typename R> struct HitT { R t; int prim; };
 // so an equal t on a later leaf replaces the earlier one.  `prim` is wave-uniform, so the table reads are scalar.
 // Media are handled by the caller-supplied functor (stochastic in the reference, hittable.c:563-584).
 template <typename R, typename MediumFn>
-RT_DEV HitT<R> closest_hit_range(const SceneT<R> &sc, const PrimT<R> *prims, int first, int count, const RayT<R> &r, R tmin, R tmax, MediumFn &&medium) {
+RT_DEV HitT<R> closest_hit_range(const SceneT<R> &sc, const PrimT<R> *prims, int first, int count, const RayT<R> &r, R tmin, R tmax, MediumFn &&medium, int src = -1) {
     HitT<R> h; h.t = tmax; h.prim = -1;
     int cur_chain = 0; RayT<R> rl = r;
     for (int i = first; i < first + count; ++i) {
@@ -111,13 +144,50 @@ RT_DEV HitT<R> closest_hit_range(const SceneT<R> &sc, const PrimT<R> *prims, int
         R t;
         if (p.type == RTC_PRIM_MEDIUM) { if (medium(i, h.t, t)) { h.t = t; h.prim = i; } continue; }
         if (p.chain != cur_chain) { cur_chain = p.chain; rl = chain_enter(sc, cur_chain, r); }
-        if (leaf_t(p, rl, tmin, h.t, t)) { h.t = t; h.prim = i; }
+        if (leaf_t(p, rl, tmin, h.t, t, i == src)) { h.t = t; h.prim = i; }
     }
     return h;
 }
+// src = the leaf the ray starts on (FP32 path tracer only; -1 = none): see sphere_leave_t.
 template <typename R, typename MediumFn>
-RT_DEV HitT<R> closest_hit_linear(const SceneT<R> &sc, const RayT<R> &r, R tmin, R tmax, MediumFn &&medium) {
-    return closest_hit_range<R>(sc, sc.prims, 0, sc.n_prims, r, tmin, tmax, medium);
+RT_DEV HitT<R> closest_hit_linear(const SceneT<R> &sc, const RayT<R> &r, R tmin, R tmax, MediumFn &&medium, int src = -1) {
+    return closest_hit_range<R>(sc, sc.prims, 0, sc.n_prims, r, tmin, tmax, medium, src);
+}
+
+// aabb_hit (aabb.c:33-63) with the reference's mixed precision (F9): the reciprocal is a FLOAT division, the slab
+// distances are double x (double)float products; swap on a negative reciprocal; strict tmax <= tmin rejects.
+template <typename R> RT_DEV bool aabb_hit_ref(const double *b, const RayT<R> &r, R tmin, R tmax) {
+    const R o[3] = {r.o.x, r.o.y, r.o.z}, d[3] = {r.d.x, r.d.y, r.d.z};
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const float invD = 1.0f / (float)d[a];
+        R t0 = ((R)b[a] - o[a]) * (R)invD, t1 = ((R)b[3 + a] - o[a]) * (R)invD;
+        if (invD < 0.0f) { const R sw = t0; t0 = t1; t1 = sw; }
+        tmin = t0 > tmin ? t0 : tmin;
+        tmax = t1 < tmax ? t1 : tmax;
+        if (tmax <= tmin) return false;
+    }
+    return true;
+}
+// The reference's own traversal, step by step (RefStep, rtc_tables.h): list scans in insertion order, BVH nodes
+// left subtree then right subtree, each node culled by aabb_hit against the closest t found so far
+// (bvh_node_hit, hittable.c:485-490).  Bit-exact primitive ids even where two leaves share a t.
+template <typename R, typename MediumFn>
+RT_DEV HitT<R> closest_hit_ref(const SceneT<R> &sc, const RayT<R> &r, R tmin, R tmax, MediumFn &&medium) {
+    HitT<R> h; h.t = tmax; h.prim = -1;
+    int i = 0;
+    while (i < sc.n_ref_steps) {
+        const RefStep s = sc.ref_steps[i];
+        if (s.kind == RTC_STEP_NODE) {
+            const RayT<R> rl = s.chain ? chain_enter(sc, s.chain, r) : r;
+            i += aabb_hit_ref<R>(sc.ref_boxes + 6 * (size_t)s.b, rl, tmin, h.t) ? 1 : s.a;
+            continue;
+        }
+        const HitT<R> g = closest_hit_range<R>(sc, sc.prims, s.a, s.b, r, tmin, h.t, medium);
+        if (g.prim >= 0) h = g;
+        ++i;
+    }
+    return h;
 }
 
 // Same result from the linear BVH: any visiting order, so ties are broken explicitly -- the leaf with the
@@ -150,7 +220,7 @@ struct LdsStack {
     RT_DEV bool pop(int &x) { if (sp == 0) return false; --sp; x = base[sp * stride]; return true; }
 };
 template <typename R, typename Stack, typename MediumFn>
-RT_DEV HitT<R> closest_hit_bvh(const SceneT<R> &sc, const RayT<R> &r, R tmin, R tmax, Stack &stack, MediumFn &&medium) {
+RT_DEV HitT<R> closest_hit_bvh(const SceneT<R> &sc, const RayT<R> &r, R tmin, R tmax, Stack &stack, MediumFn &&medium, int src = -1) {
     HitT<R> h; h.t = tmax; h.prim = -1;
     const V3<R> inv = mk3<R>(Mth<R>::div((R)1, r.d.x), Mth<R>::div((R)1, r.d.y), Mth<R>::div((R)1, r.d.z));
     int node = 0;
@@ -169,7 +239,7 @@ RT_DEV HitT<R> closest_hit_bvh(const SceneT<R> &sc, const RayT<R> &r, R tmin, R 
                     R t;
                     if (p.type == RTC_PRIM_MEDIUM) { if (medium(id, h.t, t) && !(t == h.t && id < h.prim)) { h.t = t; h.prim = id; } continue; }
                     const RayT<R> rl = p.chain ? chain_enter(sc, p.chain, r) : r;
-                    if (leaf_t(p, rl, tmin, h.t, t) && !(t == h.t && id < h.prim)) { h.t = t; h.prim = id; }
+                    if (leaf_t(p, rl, tmin, h.t, t, id == src) && !(t == h.t && id < h.prim)) { h.t = t; h.prim = id; }
                 }
             } else if (next < 0) next = ch;
             else stack.push(ch);

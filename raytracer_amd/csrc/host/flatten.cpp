@@ -103,7 +103,15 @@ struct Flattener {
         return b;
     }
 
-    bool leaf(const hittable *h, bool boundary) {
+    // kind 2 = a PRIMS step that came out of a BVH splice: its neighbours' skip counts are fixed, never extend it
+    enum { STEP_SEALED = 2 };
+    void step_prim(std::vector<RefStep> *steps, int id) {
+        if (!steps) return;
+        if (!steps->empty() && steps->back().kind == RTC_STEP_PRIMS && steps->back().a + steps->back().b == id) { steps->back().b++; return; }
+        steps->push_back(RefStep{RTC_STEP_PRIMS, 0, id, 1});
+    }
+
+    bool leaf(const hittable *h, bool boundary, std::vector<RefStep> *steps) {
         PrimT<double> p; std::memset(&p, 0, sizeof p);
         Box b = box_empty();
         if (h->kind == RT_H_SPHERE) {
@@ -134,6 +142,7 @@ struct Flattener {
         (boundary ? fs.bprims : fs.prims).push_back(p);
         (boundary ? bprim_boxes : prim_boxes).push_back(to_world(b));
         if (!boundary) {
+            step_prim(steps, (int)fs.prims.size() - 1);
             int depth = 0, flips = 0;
             for (const auto &o : cur) { if (o.type == RTC_OP_FLIP) flips ^= 1; else depth++; }
             fs.wrap_depth.push_back(depth); fs.flipped.push_back(flips);
@@ -141,18 +150,72 @@ struct Flattener {
         return true;
     }
 
-    bool walk(const hittable *h, bool boundary) {
+    // bvh_node_constructor (hittable.c:163-215, F8) replayed over the ORIGINAL member order: node box =
+    // surrounding_box(left box, right box) (aabb.c:67-84) with the (t0,t1) given to bvh_node_init; span 1 -> the same
+    // member is both children (it is visited twice); span 2 -> ordered by box min.x at times (0,0).
+    struct Sub { std::vector<RefStep> steps; rt_box box; };
+    static rt_box surround(const rt_box &a, const rt_box &b) {
+        rt_box r;
+        r.lo.x = std::fmin(a.lo.x, b.lo.x); r.lo.y = std::fmin(a.lo.y, b.lo.y); r.lo.z = std::fmin(a.lo.z, b.lo.z);
+        r.hi.x = std::fmax(a.hi.x, b.hi.x); r.hi.y = std::fmax(a.hi.y, b.hi.y); r.hi.z = std::fmax(a.hi.z, b.hi.z);
+        return r;
+    }
+    bool ref_tree(const hittable *bvh, const std::vector<std::vector<RefStep>> &msteps, int chain, int start, int end, Sub &out) {
+        const hittable_list *src = bvh->members;
+        const int span = end - start;
+        Sub l, r;
+        auto member = [&](int i, Sub &s) {
+            if (!rt_bounding_box(src->objs[i], bvh->t0, bvh->t1, &s.box)) { fs.error = "bvh member without a bounding box"; return false; }
+            s.steps = msteps[i];
+            return true;
+        };
+        if (span == 1) { if (!member(start, l)) return false; r = l; }
+        else if (span == 2) {
+            rt_box a, b; int lt = 0;
+            if (rt_bounding_box(src->objs[start], 0, 0, &a) && rt_bounding_box(src->objs[start + 1], 0, 0, &b)) lt = a.lo.x < b.lo.x;
+            if (!member(lt ? start : start + 1, l) || !member(lt ? start + 1 : start, r)) return false;
+        } else {
+            const int mid = start + span / 2;
+            if (!ref_tree(bvh, msteps, chain, start, mid, l) || !ref_tree(bvh, msteps, chain, mid, end, r)) return false;
+        }
+        out.box = surround(l.box, r.box);
+        out.steps.clear();
+        out.steps.reserve(1 + l.steps.size() + r.steps.size());
+        out.steps.push_back(RefStep{RTC_STEP_NODE, chain, (int)(1 + l.steps.size() + r.steps.size()), (int)(fs.ref_boxes.size() / 6)});
+        const double bx[6] = {out.box.lo.x, out.box.lo.y, out.box.lo.z, out.box.hi.x, out.box.hi.y, out.box.hi.z};
+        fs.ref_boxes.insert(fs.ref_boxes.end(), bx, bx + 6);
+        out.steps.insert(out.steps.end(), l.steps.begin(), l.steps.end());
+        out.steps.insert(out.steps.end(), r.steps.begin(), r.steps.end());
+        return true;
+    }
+
+    bool walk(const hittable *h, bool boundary, std::vector<RefStep> *steps) {
         switch (h->kind) {
-        case RT_H_SPHERE: case RT_H_MOVING_SPHERE: case RT_H_RECT: return leaf(h, boundary);
-        case RT_H_BOX: for (int i = 0; i < h->members->index; i++) if (!walk(h->members->objs[i], boundary)) return false; return true;
-        case RT_H_BVH: for (int i = 0; i < h->bvh_count; i++) if (!walk(h->members->objs[h->bvh_order[i]], boundary)) return false; return true;
+        case RT_H_SPHERE: case RT_H_MOVING_SPHERE: case RT_H_RECT: return leaf(h, boundary, steps);
+        case RT_H_BOX: for (int i = 0; i < h->members->index; i++) if (!walk(h->members->objs[i], boundary, steps)) return false; return true;
+        case RT_H_BVH: {
+            if (!steps) { for (int i = 0; i < h->bvh_count; i++) if (!walk(h->members->objs[h->bvh_order[i]], boundary, nullptr)) return false; return true; }
+            // leaves are numbered in visit order (bvh_order); each member's own steps are kept aside and spliced into
+            // the reference's tree afterwards
+            std::vector<std::vector<RefStep>> msteps((size_t)h->members->index);
+            for (int i = 0; i < h->bvh_count; i++) {
+                const int m = h->bvh_order[i];
+                if (!walk(h->members->objs[m], boundary, &msteps[(size_t)m])) return false;
+                for (auto &st : msteps[(size_t)m]) if (st.kind == RTC_STEP_PRIMS) st.kind = STEP_SEALED;
+            }
+            if (h->members->index == 0) return true;
+            Sub root;
+            if (!ref_tree(h, msteps, chain_id(), 0, h->members->index, root)) return false;
+            steps->insert(steps->end(), root.steps.begin(), root.steps.end());
+            return true;
+        }
         case RT_H_TRANSLATE: case RT_H_ROTATE: case RT_H_FLIP: {
             OpT<double> o; std::memset(&o, 0, sizeof o);
             if (h->kind == RT_H_TRANSLATE) { o.type = RTC_OP_TRANSLATE; o.a = h->offset.x; o.b = h->offset.y; o.c = h->offset.z; }
             else if (h->kind == RT_H_ROTATE) { o.type = RTC_OP_ROTATE; o.axis = h->axis; o.a = h->sin_theta; o.b = h->cos_theta; }
             else o.type = RTC_OP_FLIP;
             cur.push_back(o);
-            bool ok = walk(h->child, boundary);
+            bool ok = walk(h->child, boundary, steps);
             cur.pop_back();
             return ok;
         }
@@ -162,11 +225,12 @@ struct Flattener {
             p.type = RTC_PRIM_MEDIUM; p.d[0] = h->neg_inv_density; p.mat = material_id(h->mat); p.chain = chain_id();
             p.bnd_first = (int)fs.bprims.size();
             size_t first_box = bprim_boxes.size();
-            if (!walk(h->child, true)) return false;
+            if (!walk(h->child, true, nullptr)) return false;
             p.bnd_count = (int)fs.bprims.size() - p.bnd_first;
             Box b = box_empty();
             for (size_t i = first_box; i < bprim_boxes.size(); i++) box_merge(b, bprim_boxes[i]);
             fs.prims.push_back(p); prim_boxes.push_back(b);
+            step_prim(steps, (int)fs.prims.size() - 1);
             int depth = 0, flips = 0;
             for (const auto &o : cur) { if (o.type == RTC_OP_FLIP) flips ^= 1; else depth++; }
             fs.wrap_depth.push_back(depth); fs.flipped.push_back(flips);
@@ -257,7 +321,8 @@ bool flatten_scene(const hittable_list *world, const hittable_list *lights, cons
     if (!world) { out.error = "world list is NULL"; return false; }
     Flattener f(out, time0, time1);
     for (int i = 0; i < world->index; i++)
-        if (!f.walk(world->objs[i], false)) { if (out.error.empty()) out.error = "unsupported hittable in world"; return false; }
+        if (!f.walk(world->objs[i], false, &out.ref_steps)) { if (out.error.empty()) out.error = "unsupported hittable in world"; return false; }
+    for (auto &st : out.ref_steps) if (st.kind == Flattener::STEP_SEALED) st.kind = RTC_STEP_PRIMS;
     if (background) { out.background[0] = background->x; out.background[1] = background->y; out.background[2] = background->z; }
     // lights list: hittable_pdf_value / hittable_random (hittable.c:792-805,851-864) look through flip_face only;
     // anything else contributes pdf 0 and the fixed direction (1,0,0).

@@ -19,6 +19,8 @@ struct FlatScene {
     std::vector<unsigned char> image_data;
     std::vector<BvhNode> nodes;
     std::vector<int> leaf_prims;
+    std::vector<RefStep> ref_steps; // the reference's own traversal, depth-first (FP64 check path)
+    std::vector<double> ref_boxes;  // 6 doubles per RTC_STEP_NODE
     std::vector<int> wrap_depth;   // per prim: number of translate/rotate wrappers (for rtc_scene_dump_leaves)
     std::vector<int> flipped;      // per prim: parity of flip_face wrappers
     int n_media = 0;

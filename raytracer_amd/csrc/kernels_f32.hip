@@ -25,7 +25,9 @@ struct MediumF32 {
         const float inf = Mth<float>::inf();
         const HitT<float> a = closest_hit_range<float>(sc, sc.bprims, p.bnd_first, p.bnd_count, r, -inf, inf, nv);
         if (a.prim < 0) return false;
-        const HitT<float> b = closest_hit_range<float>(sc, sc.bprims, p.bnd_first, p.bnd_count, r, a.t + 0.0001f, inf, nv);
+        // rec1.t + 0.0001 (hittable.c:566): in float the 1e-4 is absorbed once |t| > ~800 and the second query would
+        // return the first root again; keep the step at least 4 ulp so it stays a step
+        const HitT<float> b = closest_hit_range<float>(sc, sc.bprims, p.bnd_first, p.bnd_count, r, a.t + fmaxf(0.0001f, fabsf(a.t) * 4.8e-7f), inf, nv);
         if (b.prim < 0) return false;
         float t1 = a.t, t2 = b.t;
         if (t1 < tmin) t1 = tmin;
@@ -69,10 +71,12 @@ __global__ void __launch_bounds__(256) k_pathtrace_mega(SceneT<float> sc, Camera
     int s_next = P.s_begin, depth = 0;
     uint32_t s_cur = 0;
     bool alive = false;
+    int src = -1;                                                          // leaf the current ray starts on (-1: camera / inside a medium)
     PathState ps;
     ps.T = f3mk(1, 1, 1); ps.L = f3mk(0, 0, 0); ps.ray.o = f3mk(0, 0, 0); ps.ray.d = f3mk(0, 0, 1); ps.ray.time = 0;
 
     for (;;) {
+        if (P.max_depth <= 0) break;                                       // ray.c:52: depth 0 -> every sample is black (wave-uniform)
         if (!alive && valid && s_next < P.s_end) {                         // main.c:150-152 + camera.c:46-53
             s_cur = (uint32_t)s_next++;
             const Rng4 c = rng_block(pixel, s_cur, RT_TAG_CAMERA, P.seed_lo, P.seed_hi);
@@ -82,7 +86,7 @@ __global__ void __launch_bounds__(256) k_pathtrace_mega(SceneT<float> sc, Camera
             if (P.use_time) tm = cam.time0 + (cam.time1 - cam.time0) * rng_block(pixel, s_cur, RT_TAG_TIME, P.seed_lo, P.seed_hi).x;
             ps.ray = camera_ray<float>(cam, u, v, dx, dy, tm);
             ps.T = f3mk(1, 1, 1); ps.L = f3mk(0, 0, 0);
-            depth = 0; alive = true;
+            depth = 0; alive = true; src = -1;
         }
         if (__builtin_amdgcn_ballot_w64(alive) == 0) break;                // every lane of the wave is out of samples
         if (alive) {
@@ -91,9 +95,9 @@ __global__ void __launch_bounds__(256) k_pathtrace_mega(SceneT<float> sc, Camera
             HitT<float> h;
             if (BVH) {
                 LdsStack stack(lds_stack + threadIdx.x, 256, kStackCap);
-                h = closest_hit_bvh<float>(sc, ps.ray, 0.001f, Mth<float>::inf(), stack, medium);   // ray.c:56
+                h = closest_hit_bvh<float>(sc, ps.ray, 0.001f, Mth<float>::inf(), stack, medium, src);   // ray.c:56
             } else {
-                h = closest_hit_linear<float>(sc, ps.ray, 0.001f, Mth<float>::inf(), medium);
+                h = closest_hit_linear<float>(sc, ps.ray, 0.001f, Mth<float>::inf(), medium, src);
             }
             ++nrays;
             int status;
@@ -107,6 +111,7 @@ __global__ void __launch_bounds__(256) k_pathtrace_mega(SceneT<float> sc, Camera
                 const RecT<float> rec = resolve_hit<float>(sc, ps.ray, p, h.t, material_needs_uv(sc, m));
                 const Rng4 xi = rng_block(pixel, s_cur, (uint32_t)depth, P.seed_lo, P.seed_hi);
                 status = shade_hit(sc, ps, rec, P.integrator, P.light_weight, xi);
+                src = p.type == RTC_PRIM_MEDIUM ? -1 : h.prim;
             }
             ++depth;
             if (status == RT_TERMINATE || depth >= P.max_depth) {          // ray.c:52: depth exhausted adds nothing
@@ -126,6 +131,23 @@ __global__ void __launch_bounds__(256) k_pathtrace_mega(SceneT<float> sc, Camera
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) total += __shfl_xor(total, off, 64);
     if (lane == 0) atomicAdd(ray_counter, (unsigned long long)total);
+}
+
+// The production traversal on its own (same code path the megakernel uses: brute-force scalar loop or the flattened
+// BVH with its LDS stack), one lane per ray.  Media are skipped.  For validating the FP32 path against the FP64 one.
+template <bool BVH>
+__global__ void __launch_bounds__(256) k_first_hit_f32(SceneT<float> sc, const float *__restrict__ rays7, size_t n, float tmin, float tmax,
+                                                        int32_t *__restrict__ prim_id, float *__restrict__ t_out) {
+    __shared__ int lds_stack[BVH ? kStackCap * 256 : 1];
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = i < n;
+    const float *a = rays7 + 7 * (live ? i : 0);
+    RayT<float> r; r.o = f3mk(a[0], a[1], a[2]); r.d = f3mk(a[3], a[4], a[5]); r.time = a[6];
+    MediumF32::Never nv;
+    HitT<float> h;
+    if (BVH) { LdsStack stack(lds_stack + threadIdx.x, 256, kStackCap); h = closest_hit_bvh<float>(sc, r, tmin, tmax, stack, nv); }
+    else h = closest_hit_linear<float>(sc, r, tmin, tmax, nv);
+    if (live) { prim_id[i] = h.prim; t_out[i] = h.prim >= 0 ? h.t : 0.0f; }
 }
 
 // write_color (ray.c:35-47): mean -> sqrt -> clamp [0, 0.999] -> *256 -> u8.  One lane per pixel.
@@ -153,6 +175,13 @@ hipError_t launch_pathtrace_mega(const SceneT<float> &sc, const CameraT<float> &
     const unsigned blocks = (unsigned)((p.n_tiles + 3) / 4);
     if (sc.n_nodes > 0) hipLaunchKernelGGL(k_pathtrace_mega<true>, dim3(blocks), dim3(256), 0, stream, sc, cam, p, accum, ray_counter);
     else hipLaunchKernelGGL(k_pathtrace_mega<false>, dim3(blocks), dim3(256), 0, stream, sc, cam, p, accum, ray_counter);
+    return hipGetLastError();
+}
+hipError_t launch_first_hit_f32(const SceneT<float> &sc, const float *rays7, size_t n, float tmin, float tmax, int32_t *prim_id, float *t, hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    const unsigned blocks = (unsigned)((n + 255) / 256);
+    if (sc.n_nodes > 0) hipLaunchKernelGGL(k_first_hit_f32<true>, dim3(blocks), dim3(256), 0, stream, sc, rays7, n, tmin, tmax, prim_id, t);
+    else hipLaunchKernelGGL(k_first_hit_f32<false>, dim3(blocks), dim3(256), 0, stream, sc, rays7, n, tmin, tmax, prim_id, t);
     return hipGetLastError();
 }
 hipError_t launch_tonemap_u8(const float4 *accum, int n_pixels, unsigned char *rgb, hipStream_t stream) {

@@ -13,8 +13,8 @@ struct NoMedium { __device__ bool operator()(int, double, double &) const { retu
 
 __device__ void first_hit_one(const SceneT<double> &sc, const RayT<double> &r, double tmin, double tmax,
                               int32_t *prim_id, double *t_out, double *rec12) {
-    NoMedium nm; LocalStack stack;
-    HitT<double> h = sc.n_nodes > 0 ? closest_hit_bvh<double>(sc, r, tmin, tmax, stack, nm) : closest_hit_linear<double>(sc, r, tmin, tmax, nm);
+    NoMedium nm;
+    const HitT<double> h = closest_hit_ref<double>(sc, r, tmin, tmax, nm);   // the reference's tree and culling, not the production BVH
     *prim_id = h.prim;
     *t_out = h.prim >= 0 ? h.t : 0.0;
     if (rec12) {

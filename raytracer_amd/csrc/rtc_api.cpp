@@ -38,7 +38,7 @@ struct DevBuf {
 };
 
 template <typename R> struct DeviceTables {
-    DevBuf prims, bprims, ops, chains, materials, textures, lights, perlin_vec, perlin_perm, images, image_data, nodes, leaf_prims;
+    DevBuf prims, bprims, ops, chains, materials, textures, lights, perlin_vec, perlin_perm, images, image_data, nodes, leaf_prims, ref_steps, ref_boxes;
     SceneT<R> view;
     bool ready = false;
 };
@@ -50,7 +50,7 @@ template <typename R> MaterialT<R> conv(const MaterialT<double> &s) { MaterialT<
 template <typename R> TextureT<R> conv(const TextureT<double> &s) { TextureT<R> d; d.type = s.type; d.a = s.a; d.b = s.b; d.pad = 0; for (int i = 0; i < 4; i++) d.v[i] = (R)s.v[i]; return d; }
 template <typename R> LightT<R> conv(const LightT<double> &s) { LightT<R> d; d.kind = s.kind; d.axis = s.axis; d.pad0 = d.pad1 = 0; for (int i = 0; i < 8; i++) d.d[i] = (R)s.d[i]; return d; }
 
-template <typename R> hipError_t upload_tables(const FlatScene &fs, DeviceTables<R> &dt) {
+template <typename R> hipError_t upload_tables(const FlatScene &fs, DeviceTables<R> &dt, bool with_ref_steps) {
     hipError_t e;
 #define UP(buf, vec) do { e = dt.buf.upload((vec).data(), (vec).size() * sizeof((vec)[0])); if (e != hipSuccess) return e; } while (0)
     std::vector<PrimT<R>> prims, bprims; for (const auto &x : fs.prims) prims.push_back(conv<R>(x)); for (const auto &x : fs.bprims) bprims.push_back(conv<R>(x));
@@ -61,6 +61,7 @@ template <typename R> hipError_t upload_tables(const FlatScene &fs, DeviceTables
     std::vector<R> pvec = convert_vec<R>(fs.perlin_vec);
     UP(prims, prims); UP(bprims, bprims); UP(ops, ops); UP(chains, fs.chains); UP(materials, mats); UP(textures, texs); UP(lights, lights);
     UP(perlin_vec, pvec); UP(perlin_perm, fs.perlin_perm); UP(images, fs.images); UP(image_data, fs.image_data); UP(nodes, fs.nodes); UP(leaf_prims, fs.leaf_prims);
+    if (with_ref_steps) { UP(ref_steps, fs.ref_steps); UP(ref_boxes, fs.ref_boxes); }
 #undef UP
     SceneT<R> &v = dt.view;
     v.prims = (const PrimT<R> *)dt.prims.p; v.n_prims = (int)fs.prims.size();
@@ -72,6 +73,8 @@ template <typename R> hipError_t upload_tables(const FlatScene &fs, DeviceTables
     v.perlin_vec = (const R *)dt.perlin_vec.p; v.perlin_perm = (const int *)dt.perlin_perm.p;
     v.images = (const ImageDesc *)dt.images.p; v.image_data = (const unsigned char *)dt.image_data.p;
     v.nodes = (const BvhNode *)dt.nodes.p; v.leaf_prims = (const int *)dt.leaf_prims.p; v.n_nodes = (int)fs.nodes.size();
+    v.ref_steps = (const RefStep *)dt.ref_steps.p; v.ref_boxes = (const double *)dt.ref_boxes.p;
+    v.n_ref_steps = with_ref_steps ? (int)fs.ref_steps.size() : 0;
     v.n_media = fs.n_media;
     for (int i = 0; i < 3; i++) v.background[i] = (R)fs.background[i];
     dt.ready = true;
@@ -128,7 +131,7 @@ rtc_scene *rtc_scene_build(const hittable_list *world, const hittable_list *ligh
     // brute force up to 64 leaves: the uniform loop runs out of SGPR-fed scalar loads; above that the linear BVH wins
     if (!flatten_scene(world, lights, background, time0, time1, 64, s->flat)) { g_error = "flatten: " + s->flat.error; delete s; return nullptr; }
     if (hipGetDevice(&s->device) != hipSuccess) { g_error = "rtc_scene_build: no current HIP device"; delete s; return nullptr; }
-    hipError_t e = upload_tables<float>(s->flat, s->f32);
+    hipError_t e = upload_tables<float>(s->flat, s->f32, false);
     unsigned long long zero = 0;
     if (e == hipSuccess) e = s->ray_counter.upload(&zero, sizeof zero);
     if (e != hipSuccess) { g_error = std::string("rtc_scene_build: upload failed: ") + hipGetErrorString(e); delete s; return nullptr; }
@@ -164,7 +167,7 @@ int rtc_scene_dump_leaves(const rtc_scene *scene, double *out16, int cap) {
 static int ensure_f64(rtc_scene *s) {
     if (s->device < 0) return fail(RTC_ERR_DEVICE, "scene was flattened on the host only (rtc_scene_flatten_only): no device tables");
     if (s->f64.ready) return RTC_OK;
-    HIP_TRY(upload_tables<double>(s->flat, s->f64));
+    HIP_TRY(upload_tables<double>(s->flat, s->f64, true));
     return RTC_OK;
 }
 
@@ -209,6 +212,26 @@ int rtc_primary_first_hit_f64(const rtc_scene *scene_c, const camera *cam, const
     return RTC_OK;
 }
 
+int rtc_first_hit_f32(const rtc_scene *scene_c, const double *rays7, size_t n, double tmin, double tmax, int32_t *prim_id, float *t) {
+    rtc_scene *s = const_cast<rtc_scene *>(scene_c);
+    if (!s || (!rays7 && n) || !prim_id || !t) return fail(RTC_ERR_ARG, "rtc_first_hit_f32: null argument");
+    if (s->device < 0) return fail(RTC_ERR_DEVICE, "scene was flattened on the host only (rtc_scene_flatten_only): no device tables");
+    if (n == 0) return RTC_OK;
+    std::lock_guard<std::mutex> lk(s->mu);
+    std::vector<float> rf(n * 7);
+    for (size_t i = 0; i < n * 7; i++) rf[i] = (float)rays7[i];
+    DevBuf d_rays, d_prim, d_t;
+    HIP_TRY(d_rays.upload(rf.data(), rf.size() * sizeof(float)));
+    HIP_TRY(hipMalloc(&d_prim.p, n * sizeof(int32_t)));
+    HIP_TRY(hipMalloc(&d_t.p, n * sizeof(float)));
+    const float tmaxf = tmax > 3.0e38 ? __builtin_huge_valf() : (float)tmax;
+    HIP_TRY(launch_first_hit_f32(s->f32.view, (const float *)d_rays.p, n, (float)tmin, tmaxf, (int32_t *)d_prim.p, (float *)d_t.p, nullptr));
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(prim_id, d_prim.p, n * sizeof(int32_t), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(t, d_t.p, n * sizeof(float), hipMemcpyDeviceToHost));
+    return RTC_OK;
+}
+
 static int check_settings(const rtc_settings *st) {
     if (!st) return fail(RTC_ERR_ARG, "settings is NULL");
     if (st->width < 2 || st->height < 2) return fail(RTC_ERR_ARG, "width and height must be >= 2 (the reference divides by W-1, H-1)");
@@ -239,7 +262,7 @@ int rtc_render_device(const rtc_scene *scene_c, const camera *cam, const rtc_set
     p.use_time = camf.time0 != camf.time1;
     HIP_TRY(hipMemsetAsync(s->ray_counter.p, 0, sizeof(unsigned long long), stream));
     HIP_TRY(hipEventRecord(ss.ev0, stream));
-    if (p.max_depth > 0) HIP_TRY(launch_pathtrace_mega(s->f32.view, camf, p, (float4 *)accum_dev, (unsigned long long *)s->ray_counter.p, stream));
+    HIP_TRY(launch_pathtrace_mega(s->f32.view, camf, p, (float4 *)accum_dev, (unsigned long long *)s->ray_counter.p, stream));
     HIP_TRY(hipEventRecord(ss.ev1, stream));
     ss.samples = (uint64_t)st->width * st->height * (uint64_t)(st->sample_end - st->sample_begin);
     ss.launches = 1; ss.pending = true;

@@ -37,6 +37,15 @@ struct ImageDesc { int width, height; uint32_t offset, pad; };                  
 // child >= 0: inner node index, count == 0;  count > 0: leaf, child = first slot in leaf_prims.
 struct alignas(16) BvhNode { float lo0[3]; int child0; float hi0[3]; int count0; float lo1[3]; int child1; float hi1[3]; int count1; };
 
+// One step of the REFERENCE's own traversal -- the hittable_list scan (hittable_list.c:125-143) with bvh_node_hit's
+// recursion (hittable.c:485-490) unrolled depth-first, left subtree before right.  Used by the FP64 check path only: the
+// reference's float-reciprocal aabb_hit (aabb.c:33-63, F9) decides which of two leaves with EQUAL t is visited at all, so
+// bit-exact primitive ids need the reference's tree and its culling arithmetic, not just its leaf order.
+//   RTC_STEP_PRIMS: scan prims [a, a+b) in order (later equal t replaces);
+//   RTC_STEP_NODE : aabb_hit of ref_boxes[b] for the ray taken through chain `chain`; on a miss skip `a` steps.
+enum { RTC_STEP_PRIMS = 0, RTC_STEP_NODE = 1 };
+struct RefStep { int kind, chain, a, b; };
+
 template <typename R> struct SceneT {
     const PrimT<R> *prims;   int n_prims;
     const PrimT<R> *bprims;  int n_bprims;
@@ -47,6 +56,7 @@ template <typename R> struct SceneT {
     const R *perlin_vec;     const int *perlin_perm;   // per noise slot: 768 reals, 768 ints
     const ImageDesc *images; const unsigned char *image_data;
     const BvhNode *nodes;    const int *leaf_prims; int n_nodes;   // n_nodes == 0: brute-force loop over prims
+    const RefStep *ref_steps; const double *ref_boxes; int n_ref_steps;   // FP64 check path; boxes = min xyz, max xyz
     int n_media;             // media among prims (stochastic hits)
     R background[3];
 };

@@ -34,7 +34,8 @@ typedef struct rtc_settings {
     int integrator;              /* 0 = 03 mixture PDF (ray.c:50-84), 1 = 02 attenuation (02 main.c:44-63), 2 = 01 sky (01 main.c:39-65) */
     uint64_t seed;               /* Philox key; the reference uses unseeded rand() (utils.h:23) */
     double mixture_light_weight; /* 0.1 (ray.c:72) */
-    int kernel;                  /* 0 = auto, 1 = persistent-thread megakernel, 2 = wavefront queues */
+    int kernel;                  /* 0 = auto, 1 = general megakernel (BVH, media, textures), 2 = small-scene megakernel
+                                    (<= 64 rect/sphere leaves, solid textures; RTC_ERR_SCENE when the scene is not eligible) */
     int reserved;
 } rtc_settings;
 
@@ -45,7 +46,9 @@ typedef struct rtc_stats {
     double   kernel_ms;          /* HIP-event time of the path-tracing kernel(s) on the launch stream */
     double   total_ms;           /* whole call incl. uploads/downloads */
     int      kernel_launches;
-    int      kernel_used;        /* 1 megakernel, 2 wavefront */
+    int      kernel_used;        /* 1 general megakernel, 2 small-scene megakernel */
+    uint64_t wave_iterations;    /* bounce iterations summed over waves: rays / (64 * wave_iterations) = fraction of lane
+                                    slots that traced a ray (lanes idle at the tail of their tile count against it) */
 } rtc_stats;
 
 /* Probe the current device.  0 when a gfx950-class GPU is usable.  No reference counterpart. */

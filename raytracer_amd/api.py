@@ -17,7 +17,8 @@ class RtcError(RuntimeError):
 
 
 def library_path():
-    return os.path.join(_HERE, "librtc.so")
+    # RTC_LIB: another build of the same library (kernel experiments); never a different implementation
+    return os.environ.get("RTC_LIB") or os.path.join(_HERE, "librtc.so")
 
 
 class Vec3(C.Structure):
@@ -42,7 +43,7 @@ class RtcSettings(C.Structure):
 
 class RtcStats(C.Structure):
     _fields_ = [("samples", C.c_uint64), ("rays", C.c_uint64), ("kernel_ms", C.c_double), ("total_ms", C.c_double),
-                ("kernel_launches", C.c_int), ("kernel_used", C.c_int)]
+                ("kernel_launches", C.c_int), ("kernel_used", C.c_int), ("wave_iterations", C.c_uint64)]
 
 
 SCENES = dict(simple=0, cornell=1, final=2, book1=3, cornell02=4, cornell_smoke=5, two_spheres=6, two_perlin=7,
@@ -71,6 +72,13 @@ def lib():
     global _LIB
     if _LIB is not None:
         return _LIB
+    # A process that also uses torch must end up with ONE HIP runtime: torch bundles its own libamdhip64, librtc.so
+    # links the system one, and whichever is loaded second finds "no HIP GPUs".  Loading torch first makes librtc.so
+    # resolve against torch's copy (same SONAME).  A C host without torch is not affected.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     path = library_path()
     if not os.path.exists(path):
         raise RtcError(f"{path} is missing: build it with `make -C raytracer_amd/csrc` (no CPU fallback exists)")
@@ -241,7 +249,8 @@ class Scene:
         st = RtcStats()
         _check(lib().rtc_render_stats(self.handle, stream, C.byref(st)), "rtc_render_stats")
         return dict(samples=st.samples, rays=st.rays, kernel_ms=st.kernel_ms, total_ms=st.total_ms,
-                    kernel_launches=st.kernel_launches, kernel_used=st.kernel_used)
+                    kernel_launches=st.kernel_launches, kernel_used=st.kernel_used, wave_iterations=st.wave_iterations,
+                    lane_fill=(st.rays / (64.0 * st.wave_iterations) if st.wave_iterations else 0.0))
 
 
 def build_named_scene(name, arg=0, aspect=None, seed=1, host_only=False):

@@ -14,9 +14,12 @@ typedef V3<float> f3;
 
 // ---- Philox4x32-10 (Salmon et al., SC'11) --------------------------------------------------------
 struct U4 { uint32_t x, y, z, w; };
+#ifndef RT_PHILOX_ROUNDS
+#define RT_PHILOX_ROUNDS 10
+#endif
 RT_DEV U4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
 #pragma unroll
-    for (int r = 0; r < 10; ++r) {
+    for (int r = 0; r < RT_PHILOX_ROUNDS; ++r) {
         const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
         const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
         c1 = (uint32_t)p1; c3 = (uint32_t)p0; c0 = n0; c2 = n2;

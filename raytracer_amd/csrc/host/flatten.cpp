@@ -7,6 +7,7 @@
 #include "flatten.h"
 
 #include <algorithm>
+#include <array>
 #include <cmath>
 #include <cstring>
 #include <map>
@@ -314,6 +315,84 @@ struct Builder {
     }
 };
 
+// Small-scene pack: eligible when every leaf is a rect or a sphere, there are at most 64 of them, and every
+// lambertian / light texture is a solid colour (so the colour can be resolved here, once, instead of per hit).
+void build_small_pack(FlatScene &fs) {
+    fs.small_ok = false;
+    const size_t n = fs.prims.size();
+    if (n == 0 || n > RTC_SMALL_MAX_LEAVES || fs.n_media) return;
+    std::map<int, int> xform_of_chain;            // chain id -> xform id (0 = identity)
+    std::vector<SmallXform> xf(1);
+    std::vector<std::array<double, 12>> xfd(1);
+    { SmallXform &I = xf[0]; for (int i = 0; i < 9; i++) I.m[i] = (i % 4 == 0); I.b[0] = I.b[1] = I.b[2] = 0; xfd[0] = {1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0}; }
+    auto chain_xform = [&](int chain, bool &wrapped, bool &flip) -> int {
+        const ChainRange cr = fs.chains[chain];
+        wrapped = false; flip = false;
+        double M[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, b[3] = {0, 0, 0};
+        for (int i = 0; i < cr.count; i++) {
+            const OpT<double> &o = fs.ops[cr.first + i];
+            if (o.type == RTC_OP_FLIP) { flip = !flip; continue; }
+            wrapped = true;
+            if (o.type == RTC_OP_TRANSLATE) { b[0] -= o.a; b[1] -= o.b; b[2] -= o.c; continue; }
+            // rotate_hit enters with rotatePoint(p, -sin, cos, axis) (hittable.c:542-545, pair choice F10)
+            const double s = -o.a, c = o.b;
+            double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+            if (o.axis == RTC_ROT_X) { R[0] = c; R[1] = -s; R[3] = s; R[4] = c; }
+            else if (o.axis == RTC_ROT_Y) { R[0] = c; R[2] = s; R[6] = -s; R[8] = c; }
+            else { R[4] = c; R[5] = -s; R[7] = s; R[8] = c; }
+            double M2[9], b2[3];
+            for (int r = 0; r < 3; r++) { for (int k = 0; k < 3; k++) M2[3 * r + k] = R[3 * r] * M[k] + R[3 * r + 1] * M[3 + k] + R[3 * r + 2] * M[6 + k]; b2[r] = R[3 * r] * b[0] + R[3 * r + 1] * b[1] + R[3 * r + 2] * b[2]; }
+            std::memcpy(M, M2, sizeof M); std::memcpy(b, b2, sizeof b);
+        }
+        if (!wrapped) return 0;
+        auto it = xform_of_chain.find(chain);
+        if (it != xform_of_chain.end()) return it->second;
+        SmallXform x; std::array<double, 12> xd;
+        for (int i = 0; i < 9; i++) { x.m[i] = (float)M[i]; xd[i] = M[i]; }
+        for (int i = 0; i < 3; i++) { x.b[i] = (float)b[i]; xd[9 + i] = b[i]; }
+        const int id = (int)xf.size();
+        xf.push_back(x); xfd.push_back(xd); xform_of_chain[chain] = id;
+        return id;
+    };
+    std::vector<SmallLeaf> leaves(n); std::vector<SmallShade> shade(n);
+    bool any_fuzz = false;
+    for (size_t i = 0; i < n; i++) {
+        const PrimT<double> &p = fs.prims[i];
+        if (p.type != RTC_PRIM_RECT && p.type != RTC_PRIM_SPHERE) return;
+        const MaterialT<double> &m = fs.materials[p.mat];
+        SmallLeaf &L = leaves[i]; SmallShade &S = shade[i];
+        std::memset(&L, 0, sizeof L); std::memset(&S, 0, sizeof S);
+        bool wrapped, flip;
+        const int x = chain_xform(p.chain, wrapped, flip);
+        if ((int)xf.size() > RTC_SMALL_MAX_XFORMS) return;
+        const double *M = xfd[x].data(), *b = M + 9;
+        S.meta = (uint32_t)m.type | (wrapped ? RTC_SF_FORCED_FRONT : 0u) | (flip ? RTC_SF_FLIP : 0u);
+        if (m.type == RTC_MAT_METAL) { for (int k = 0; k < 3; k++) S.rgb[k] = (float)m.albedo[k]; S.param = (float)m.param; any_fuzz |= m.param > 0; }
+        else if (m.type == RTC_MAT_DIELECTRIC) { S.rgb[0] = S.rgb[1] = S.rgb[2] = 1.0f; S.param = (float)m.param; }
+        else {
+            if (m.tex < 0 || fs.textures[m.tex].type != RTC_TEX_SOLID) return;
+            for (int k = 0; k < 3; k++) S.rgb[k] = (float)fs.textures[m.tex].v[k];
+        }
+        if (p.type == RTC_PRIM_RECT) {
+            L.meta = (uint32_t)RTC_PRIM_RECT | ((uint32_t)p.axis << 2) | ((uint32_t)x << 8);
+            const int a0 = p.axis == RTC_AXIS_YZ ? 2 : 0, b0 = p.axis == RTC_AXIS_XY ? 2 : 4;   // slots of lo_a / lo_b in d[]
+            L.f[0] = (float)p.d[6]; L.f[1] = (float)p.d[a0]; L.f[2] = (float)p.d[a0 + 1]; L.f[3] = (float)p.d[b0]; L.f[4] = (float)p.d[b0 + 1];
+            const int e = p.axis == RTC_AXIS_YZ ? 0 : (p.axis == RTC_AXIS_XZ ? 1 : 2);          // outward normal = +axis unit, object space
+            for (int k = 0; k < 3; k++) S.g[k] = (float)M[3 * e + k];                           // world normal = M^T e  (row e of M)
+        } else {
+            // world-space centre: c_w = M^T (c_obj - b)
+            const double c[3] = {p.d[0] - b[0], p.d[1] - b[1], p.d[2] - b[2]};
+            double cw[3]; for (int k = 0; k < 3; k++) cw[k] = M[k] * c[0] + M[3 + k] * c[1] + M[6 + k] * c[2];
+            L.meta = (uint32_t)RTC_PRIM_SPHERE;    // xform 0: intersected in world space
+            L.f[0] = (float)cw[0]; L.f[1] = (float)cw[1]; L.f[2] = (float)cw[2]; L.f[3] = (float)(p.d[3] * p.d[3]); L.f[4] = (float)p.d[3];
+            S.meta |= RTC_SF_SPHERE;
+            for (int k = 0; k < 3; k++) S.g[k] = (float)cw[k];
+            S.g[3] = (float)(1.0 / p.d[3]);
+        }
+    }
+    fs.small_leaves = leaves; fs.small_shade = shade; fs.small_xforms = xf; fs.small_any_fuzz = any_fuzz; fs.small_ok = true;
+}
+
 }  // namespace
 
 bool flatten_scene(const hittable_list *world, const hittable_list *lights, const color *background,
@@ -338,6 +417,7 @@ bool flatten_scene(const hittable_list *world, const hittable_list *lights, cons
             } else l.kind = RTC_LIGHT_NONE;
             out.lights.push_back(l);
         }
+    build_small_pack(out);
     if ((int)out.prims.size() > bvh_threshold) {
         Builder b{f.prim_boxes, {}, out.nodes, out.leaf_prims};
         b.idx.resize(out.prims.size());

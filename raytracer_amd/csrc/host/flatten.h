@@ -21,6 +21,11 @@ struct FlatScene {
     std::vector<int> leaf_prims;
     std::vector<RefStep> ref_steps; // the reference's own traversal, depth-first (FP64 check path)
     std::vector<double> ref_boxes;  // 6 doubles per RTC_STEP_NODE
+    // small-scene pack (empty when the scene is not eligible: see build_small_pack in flatten.cpp)
+    std::vector<SmallLeaf> small_leaves;
+    std::vector<SmallShade> small_shade;
+    std::vector<SmallXform> small_xforms;
+    bool small_ok = false, small_any_fuzz = false;
     std::vector<int> wrap_depth;   // per prim: number of translate/rotate wrappers (for rtc_scene_dump_leaves)
     std::vector<int> flipped;      // per prim: parity of flip_face wrappers
     int n_media = 0;

@@ -67,7 +67,7 @@ __global__ void __launch_bounds__(256) k_pathtrace_mega(SceneT<float> sc, Camera
     const float inv_w = 1.0f / (float)(P.width - 1), inv_h = 1.0f / (float)(P.height - 1);
 
     f3 sum = f3mk(0, 0, 0);
-    unsigned nrays = 0;
+    unsigned nrays = 0, iters = 0;
     int s_next = P.s_begin, depth = 0;
     uint32_t s_cur = 0;
     bool alive = false;
@@ -89,6 +89,7 @@ __global__ void __launch_bounds__(256) k_pathtrace_mega(SceneT<float> sc, Camera
             depth = 0; alive = true; src = -1;
         }
         if (__builtin_amdgcn_ballot_w64(alive) == 0) break;                // every lane of the wave is out of samples
+        ++iters;                                                           // wave-uniform: bounce iterations of this wave
         if (alive) {
             int draws = 0;
             MediumF32 medium{sc, ps.ray, 0.001f, pixel, s_cur, (uint32_t)depth, P.seed_lo, P.seed_hi, draws};
@@ -130,7 +131,7 @@ __global__ void __launch_bounds__(256) k_pathtrace_mega(SceneT<float> sc, Camera
     unsigned total = nrays;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) total += __shfl_xor(total, off, 64);
-    if (lane == 0) atomicAdd(ray_counter, (unsigned long long)total);
+    if (lane == 0) { atomicAdd(ray_counter, (unsigned long long)total); atomicAdd(ray_counter + 1, (unsigned long long)iters); }
 }
 
 // The production traversal on its own (same code path the megakernel uses: brute-force scalar loop or the flattened

@@ -1,0 +1,238 @@
+// kernels_small.hip -- the headline kernel: persistent-thread path tracer for SMALL scenes on gfx950 (product code).
+//
+// "Small" = at most 64 rect / sphere leaves with solid-colour textures (the 03_FullTracer Cornell box: 13 leaves).  Such
+// a scene never leaves the chip: the bounce loop of ray.c:50-84 runs out of SGPRs, VGPRs and 3 KB of LDS, and HBM only
+// sees the float4 accumulator once per launch.  Design, in the order the profile asked for it:
+//   * one wave64 = one 8x8 pixel tile, a lane owns a pixel; a lane whose path ended starts its next sample in the same
+//     iteration (persistent regeneration), so > 90 % of the lane slots trace a ray until the tile runs dry;
+//   * intersection = a wave-uniform loop over SmallLeaf records: ONE 32-byte scalar load per leaf feeds 64 lanes, rect
+//     tests are sub/mul/2 fma/6 compares against a per-space reciprocal direction, wrapper stacks are pre-collapsed
+//     affine maps applied once per space, not once per leaf;
+//   * the winner's shading record (world normal or centre, resolved colour, flags) is ONE 48-byte LDS gather -- the
+//     generic path chases prim -> material -> texture through three dependent global loads;
+//   * material / pdf dispatch is a switch on the record's type; lambertian sampling uses n + uniform-sphere (the same
+//     cosine law as onb.c + random_cosine_direction, without building the basis), the mixture pdf of pdf.c:119-121;
+//   * Philox4x32-10 on (pixel, sample, bounce); 2 blocks per path start are not needed here (no lens, no moving leaf).
+// Register budget is kept under 64 VGPRs so that 8 waves per SIMD hide the scalar-load and LDS latencies.
+#include <hip/hip_runtime.h>
+
+#include "device/rt_shade.hpp"
+#include "kernels.h"
+
+namespace {
+
+struct SmallHit { float t; int leaf; };
+
+RT_DEV f3 xform_point(const SmallXform &x, f3 p) {
+    return f3mk(x.m[0] * p.x + x.m[1] * p.y + x.m[2] * p.z + x.b[0], x.m[3] * p.x + x.m[4] * p.y + x.m[5] * p.z + x.b[1],
+                x.m[6] * p.x + x.m[7] * p.y + x.m[8] * p.z + x.b[2]);
+}
+RT_DEV f3 xform_dir(const SmallXform &x, f3 d) {
+    return f3mk(x.m[0] * d.x + x.m[1] * d.y + x.m[2] * d.z, x.m[3] * d.x + x.m[4] * d.y + x.m[5] * d.z, x.m[6] * d.x + x.m[7] * d.y + x.m[8] * d.z);
+}
+RT_DEV f3 rcp3(f3 d) { return f3mk(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z)); }
+
+// hittable_list_hit (hittable_list.c:125-143) over the packed leaves; `src` = leaf the ray starts on (rt_core.hpp:
+// sphere_leave_t explains why FP32 needs it).  Later leaves with an equal t replace earlier ones, like the reference.
+RT_DEV SmallHit small_closest_hit(const SmallScene &ss, f3 ow, f3 dw, float tmin, int src) {
+    SmallHit h; h.t = Mth<float>::inf(); h.leaf = -1;
+    const f3 invw = rcp3(dw);
+    f3 o = ow, d = dw, inv = invw;
+    int cur = 0;
+    for (int i = 0; i < ss.n_leaves; ++i) {
+        const SmallLeaf lf = ss.leaves[i];                       // wave-uniform index: one s_load_dwordx8
+        const int type = lf.meta & 3, axis = (lf.meta >> 2) & 3, xf = (lf.meta >> 8) & 0xff;
+        if (type == RTC_PRIM_RECT) {
+            if (xf != cur) {                                     // wave-uniform: enter this leaf's object space once
+                cur = xf;
+                if (xf == 0) { o = ow; d = dw; inv = invw; }
+                else { const SmallXform x = ss.xforms[xf]; o = xform_point(x, ow); d = xform_dir(x, dw); inv = rcp3(d); }
+            }
+            float on, in, oa, da, ob, db;                        // normal axis n, in-plane axes a, b (rect_hit, hittable.c:494-506)
+            if (axis == RTC_AXIS_XY) { on = o.z; in = inv.z; oa = o.x; da = d.x; ob = o.y; db = d.y; }
+            else if (axis == RTC_AXIS_XZ) { on = o.y; in = inv.y; oa = o.x; da = d.x; ob = o.z; db = d.z; }
+            else { on = o.x; in = inv.x; oa = o.y; da = d.y; ob = o.z; db = d.z; }
+            const float t = (lf.f[0] - on) * in;
+            const float a = oa + t * da, b = ob + t * db;
+            const bool hit = (t >= tmin) & (t <= h.t) & (a >= lf.f[1]) & (a <= lf.f[2]) & (b >= lf.f[3]) & (b <= lf.f[4]) & (i != src);
+            h.t = hit ? t : h.t; h.leaf = hit ? i : h.leaf;
+        } else {                                                 // sphere, world space, closest-approach form (rt_core.hpp sphere_t<float>)
+            const f3 oc = ow - f3mk(lf.f[0], lf.f[1], lf.f[2]);
+            const float inv_a = __builtin_amdgcn_rcpf(len2(dw));
+            const float tc = -dot(oc, dw) * inv_a;
+            const f3 l = oc + dw * tc;
+            const float q = (lf.f[3] - len2(l)) * inv_a;
+            const float sq = __builtin_amdgcn_sqrtf(fmaxf(q, 0.0f));
+            const bool from = i == src;                          // leaving this sphere: roots are {0, 2 tc}
+            const float t0 = from ? 2.0f * tc : tc - sq, t1 = tc + sq;
+            const bool ok0 = (t0 >= tmin) & (t0 <= h.t), ok1 = (t1 >= tmin) & (t1 <= h.t) & !from;
+            const float t = ok0 ? t0 : t1;
+            const bool hit = (from | (q >= 0.0f)) & (ok0 | ok1);
+            h.t = hit ? t : h.t; h.leaf = hit ? i : h.leaf;
+        }
+    }
+    return h;
+}
+
+// hittable_list_pdf_value over the lights list (hittable_list.c:165-172, hittable.c:760-788): wave-uniform loop.
+RT_DEV float small_light_pdf(const SceneT<float> &sc, f3 o, f3 v) {
+    const float weight = __builtin_amdgcn_rcpf((float)sc.n_lights);
+    float sum = 0.0f;
+    for (int i = 0; i < sc.n_lights; ++i) sum += light_pdf_one(sc.lights[i], o, v);
+    return sum * weight;
+}
+// Duff et al. 2017 branch-free orthonormal basis (any basis around w gives the same uniform azimuth as onb.c:7-12)
+RT_DEV void basis_around(f3 w, f3 &u, f3 &v) {
+    const float sign = __builtin_copysignf(1.0f, w.z);
+    const float a = -__builtin_amdgcn_rcpf(sign + w.z), b = w.x * w.y * a;
+    u = f3mk(1.0f + sign * w.x * w.x * a, sign * b, -sign * w.x);
+    v = f3mk(b, sign + w.y * w.y * a, -w.y);
+}
+RT_DEV f3 small_light_sample(const SceneT<float> &sc, int pick, f3 o, float r1, float r2) {
+    f3 dir = f3mk(1, 0, 0);                                                                // hittable.c:861-863
+    for (int i = 0; i < sc.n_lights; ++i) {                                               // uniform loop, per-lane select
+        const LightT<float> &l = sc.lights[i];
+        if (pick != i) continue;
+        if (l.kind == RTC_LIGHT_RECT) dir = light_random_one(l, o, r1, r2);               // hittable.c:838-848
+        else if (l.kind == RTC_LIGHT_SPHERE) {                                            // hittable.c:821-835, cone towards the sphere
+            const f3 axis = f3mk(l.d[0], l.d[1], l.d[2]) - o;
+            const float d2 = len2(axis);
+            const f3 w = axis * __builtin_amdgcn_rsqf(d2);
+            f3 u, v; basis_around(w, u, v);
+            const float z = 1.0f + r2 * (__builtin_amdgcn_sqrtf(fmaxf(0.0f, 1.0f - l.d[3] * l.d[3] * __builtin_amdgcn_rcpf(d2))) - 1.0f);
+            const float s = __builtin_amdgcn_sqrtf(fmaxf(0.0f, 1.0f - z * z));
+            dir = u * (cos2pi(r1) * s) + (v * (sin2pi(r1) * s) + w * z);
+        }
+    }
+    return dir;
+}
+
+template <int INTEGRATOR>
+__global__ void __launch_bounds__(256) k_pathtrace_small(SmallScene ss, SceneT<float> sc, CameraT<float> cam, RenderParams P,
+                                                          float4 *__restrict__ accum, unsigned long long *__restrict__ counters) {
+    __shared__ SmallShade lds_shade[RTC_SMALL_MAX_LEAVES];
+    {   // 48 B x n_leaves, copied dword by dword
+        const uint32_t *src = (const uint32_t *)ss.shade;
+        uint32_t *dst = (uint32_t *)lds_shade;
+        for (int i = threadIdx.x; i < ss.n_leaves * (int)(sizeof(SmallShade) / 4); i += 256) dst[i] = src[i];
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (tile >= P.n_tiles) return;   // wave-uniform, after the only barrier
+    const int px = (tile % P.tiles_x) * 8 + (lane & 7), py = (tile / P.tiles_x) * 8 + (lane >> 3);
+    const bool valid = px < P.width && py < P.height;
+    const uint32_t pixel = (uint32_t)(py * P.width + px);
+    const float inv_w = 1.0f / (float)(P.width - 1), inv_h = 1.0f / (float)(P.height - 1);
+    const f3 bg = f3mk(sc.background[0], sc.background[1], sc.background[2]);
+
+    f3 sum = f3mk(0, 0, 0), T = f3mk(1, 1, 1), L = f3mk(0, 0, 0), ro = f3mk(0, 0, 0), rd = f3mk(0, 0, 1);
+    unsigned nrays = 0, iters = 0;
+    int s_next = P.s_begin, depth = 0, src = -1;
+    uint32_t s_cur = 0;
+    bool alive = false;
+
+    for (;;) {
+        if (P.max_depth <= 0) break;                                       // ray.c:52
+        if (!alive && valid && s_next < P.s_end) {                         // main.c:150-152 + camera.c:46-53
+            s_cur = (uint32_t)s_next++;
+            const Rng4 c = rng_block(pixel, s_cur, RT_TAG_CAMERA, P.seed_lo, P.seed_hi);
+            const float u = ((float)px + c.x) * inv_w, v = ((float)py + c.y) * inv_h;
+            float dx = 0.0f, dy = 0.0f;
+            if (cam.lens_radius > 0.0f) { const float rr = __builtin_amdgcn_sqrtf(c.z); dx = rr * cos2pi(c.w); dy = rr * sin2pi(c.w); }
+            const RayT<float> r = camera_ray<float>(cam, u, v, dx, dy, 0.0f);   // no leaf moves: the ray time is never read
+            ro = r.o; rd = r.d;
+            T = f3mk(1, 1, 1); L = f3mk(0, 0, 0);
+            depth = 0; alive = true; src = -1;
+        }
+        if (__builtin_amdgcn_ballot_w64(alive) == 0) break;
+        ++iters;
+        if (alive) {
+            const SmallHit h = small_closest_hit(ss, ro, rd, 0.001f, src);  // ray.c:56
+            ++nrays;
+            bool done;
+            if (h.leaf < 0) {
+                L = L + T * (INTEGRATOR == 2 ? sky_color(rd) : bg);
+                done = true;
+            } else {
+                const SmallShade sh = lds_shade[h.leaf];
+                const uint32_t mtype = sh.meta & 0xff;
+                const f3 p = ro + rd * h.t;
+                const f3 gv = f3mk(sh.g[0], sh.g[1], sh.g[2]);
+                const f3 n_out = (sh.meta & RTC_SF_SPHERE) ? (p - gv) * sh.g[3] : gv;
+                bool front = dot(rd, n_out) < 0.0f;                        // hit_record_set_facenormal, hittable.c:13-16
+                const f3 n = front ? n_out : -n_out;
+                if (sh.meta & RTC_SF_FORCED_FRONT) front = true;            // translate/rotate re-face an already faced normal (F11)
+                if (sh.meta & RTC_SF_FLIP) front = !front;                  // flip_face_hit, hittable.c:587-591
+                const f3 col = f3mk(sh.rgb[0], sh.rgb[1], sh.rgb[2]);
+                const Rng4 xi = rng_block(pixel, s_cur, (uint32_t)depth, P.seed_lo, P.seed_hi);
+                done = false;
+                f3 nd = rd;
+                if (mtype == RTC_MAT_LIGHT) {                               // material.c:229-235 (03: front face only, F15); no scatter
+                    if (INTEGRATOR == 1 || (INTEGRATOR == 0 && front)) L = L + T * col;
+                    done = true;
+                } else if (mtype == RTC_MAT_METAL) {                        // material.c:130-138 / 02 material.c:132-141
+                    nd = reflect(normalize(rd), n);
+                    if (ss.any_fuzz) nd = nd + uniform_ball(xi.x, xi.y, xi.z) * sh.param;
+                    if (INTEGRATOR != 0 && !(dot(nd, n) > 0.0f)) done = true;
+                    T = T * col;
+                } else if (mtype == RTC_MAT_DIELECTRIC) {                   // material.c:144-162
+                    RecT<float> rec; rec.n = n; rec.front = front;
+                    nd = dielectric_dir(sh.param, rd, rec, xi.x);
+                } else if (mtype == RTC_MAT_ISOTROPIC) {
+                    done = true;                                            // only reachable through a medium; none in a small scene
+                } else if (INTEGRATOR != 0) {                               // 02 material.c:120-128: normal + random unit vector
+                    nd = n + uniform_sphere(xi.x, xi.y);
+                    if (fabsf(nd.x) < 1e-8f && fabsf(nd.y) < 1e-8f && fabsf(nd.z) < 1e-8f) nd = n;
+                    T = T * col;
+                } else {                                                    // 03: ray.c:66-83, mixture of light-list and cosine pdfs
+                    const float w = P.light_weight;
+                    if (sc.n_lights > 0 && xi.x < w) {                       // pdf.c:175-181
+                        int pick = (int)((float)sc.n_lights * xi.y);         // random_int(0, n-1), utils.h:26
+                        pick = pick < sc.n_lights ? pick : sc.n_lights - 1;
+                        nd = small_light_sample(sc, pick, p, xi.z, xi.w);
+                    } else {                                                 // cosine law about n (vec3.c:97-107 + onb.c:25-30)
+                        nd = n + uniform_sphere(xi.z, xi.w);
+                        if (len2(nd) < 1e-12f) nd = n;
+                    }
+                    const float cosn = dot(n, nd) * __builtin_amdgcn_rsqf(len2(nd));
+                    const float pdf_cos = cosn > 0.0f ? cosn * RT_INV_PI : 0.0f;      // pdf.c:100-103 == material.c:205-208
+                    const float pdf_light = sc.n_lights > 0 ? small_light_pdf(sc, p, nd) : 0.0f;
+                    const float pdf_val = w * pdf_light + (1.0f - w) * pdf_cos;       // pdf.c:119-121
+                    // scattering pdf 0: the reference recurses and multiplies by 0; pdf_val 0: 0/0 (scrubbed) -- nothing more arrives
+                    if (!(pdf_cos > 0.0f) || !(pdf_val > 0.0f)) done = true;
+                    else T = T * (col * (pdf_cos * __builtin_amdgcn_rcpf(pdf_val)));
+                }
+                ro = p; rd = nd; src = h.leaf;
+            }
+            ++depth;
+            if (done || depth >= P.max_depth) {
+                alive = false;
+                const bool finite = (fabsf(L.x) < 3.0e38f) && (fabsf(L.y) < 3.0e38f) && (fabsf(L.z) < 3.0e38f);
+                if (finite) sum = sum + L;
+            }
+        }
+    }
+    if (valid) {
+        float4 a = accum[pixel];
+        a.x += sum.x; a.y += sum.y; a.z += sum.z; a.w += (float)(P.s_end - P.s_begin);
+        accum[pixel] = a;
+    }
+    unsigned total = nrays;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) total += __shfl_xor(total, off, 64);
+    if (lane == 0) { atomicAdd(counters, (unsigned long long)total); atomicAdd(counters + 1, (unsigned long long)iters); }
+}
+
+}  // namespace
+
+hipError_t launch_pathtrace_small(const SmallScene &ss, const SceneT<float> &sc, const CameraT<float> &cam, const RenderParams &p,
+                                  float4 *accum, unsigned long long *counters, hipStream_t stream) {
+    if (p.n_tiles <= 0 || p.s_end <= p.s_begin) return hipSuccess;
+    if (ss.n_leaves <= 0 || ss.n_leaves > RTC_SMALL_MAX_LEAVES) return hipErrorInvalidValue;
+    const unsigned blocks = (unsigned)((p.n_tiles + 3) / 4);
+    if (p.integrator == 0) hipLaunchKernelGGL(k_pathtrace_small<0>, dim3(blocks), dim3(256), 0, stream, ss, sc, cam, p, accum, counters);
+    else if (p.integrator == 1) hipLaunchKernelGGL(k_pathtrace_small<1>, dim3(blocks), dim3(256), 0, stream, ss, sc, cam, p, accum, counters);
+    else hipLaunchKernelGGL(k_pathtrace_small<2>, dim3(blocks), dim3(256), 0, stream, ss, sc, cam, p, accum, counters);
+    return hipGetLastError();
+}

@@ -90,7 +90,7 @@ template <typename R> CameraT<R> camera_tables(const camera *c) {
     return d;
 }
 
-struct StreamState { hipEvent_t ev0 = nullptr, ev1 = nullptr; uint64_t samples = 0; int launches = 0; bool pending = false; double total_ms = 0; };
+struct StreamState { hipEvent_t ev0 = nullptr, ev1 = nullptr; uint64_t samples = 0; int launches = 0; int kernel = 0; bool pending = false; double total_ms = 0; };
 
 }  // namespace
 
@@ -100,6 +100,8 @@ struct rtc_scene {
     DeviceTables<float> f32;
     DeviceTables<double> f64;
     DevBuf ray_counter;
+    DevBuf small_leaves, small_shade, small_xforms;
+    SmallScene small{};   // n_leaves == 0: not eligible
     std::map<void *, StreamState> streams;
     std::mutex mu;
     ~rtc_scene() { for (auto &kv : streams) { if (kv.second.ev0) (void)hipEventDestroy(kv.second.ev0); if (kv.second.ev1) (void)hipEventDestroy(kv.second.ev1); } }
@@ -132,8 +134,18 @@ rtc_scene *rtc_scene_build(const hittable_list *world, const hittable_list *ligh
     if (!flatten_scene(world, lights, background, time0, time1, 64, s->flat)) { g_error = "flatten: " + s->flat.error; delete s; return nullptr; }
     if (hipGetDevice(&s->device) != hipSuccess) { g_error = "rtc_scene_build: no current HIP device"; delete s; return nullptr; }
     hipError_t e = upload_tables<float>(s->flat, s->f32, false);
-    unsigned long long zero = 0;
-    if (e == hipSuccess) e = s->ray_counter.upload(&zero, sizeof zero);
+    unsigned long long zero[4] = {0, 0, 0, 0};   // [0] rays, [1] wave bounce-iterations
+    if (e == hipSuccess) e = s->ray_counter.upload(zero, sizeof zero);
+    if (e == hipSuccess && s->flat.small_ok) {
+        const FlatScene &fs = s->flat;
+        e = s->small_leaves.upload(fs.small_leaves.data(), fs.small_leaves.size() * sizeof(SmallLeaf));
+        if (e == hipSuccess) e = s->small_shade.upload(fs.small_shade.data(), fs.small_shade.size() * sizeof(SmallShade));
+        if (e == hipSuccess) e = s->small_xforms.upload(fs.small_xforms.data(), fs.small_xforms.size() * sizeof(SmallXform));
+        s->small.leaves = (const SmallLeaf *)s->small_leaves.p; s->small.shade = (const SmallShade *)s->small_shade.p;
+        s->small.xforms = (const SmallXform *)s->small_xforms.p;
+        s->small.n_leaves = (int)fs.small_leaves.size(); s->small.n_xforms = (int)fs.small_xforms.size();
+        s->small.any_fuzz = fs.small_any_fuzz;
+    }
     if (e != hipSuccess) { g_error = std::string("rtc_scene_build: upload failed: ") + hipGetErrorString(e); delete s; return nullptr; }
     return s;
 }
@@ -260,9 +272,14 @@ int rtc_render_device(const rtc_scene *scene_c, const camera *cam, const rtc_set
     p.tiles_x = (st->width + 7) / 8; p.tiles_y = (st->height + 7) / 8; p.n_tiles = p.tiles_x * p.tiles_y;
     const CameraT<float> camf = camera_tables<float>(cam);
     p.use_time = camf.time0 != camf.time1;
-    HIP_TRY(hipMemsetAsync(s->ray_counter.p, 0, sizeof(unsigned long long), stream));
+    HIP_TRY(hipMemsetAsync(s->ray_counter.p, 0, 4 * sizeof(unsigned long long), stream));
     HIP_TRY(hipEventRecord(ss.ev0, stream));
-    HIP_TRY(launch_pathtrace_mega(s->f32.view, camf, p, (float4 *)accum_dev, (unsigned long long *)s->ray_counter.p, stream));
+    const bool small = st->kernel == 2 || (st->kernel == 0 && s->small.n_leaves > 0);
+    if (small && s->small.n_leaves <= 0)
+        return fail(RTC_ERR_SCENE, "kernel 2 (small-scene) needs <= 64 rect/sphere leaves with solid textures and no media");
+    if (small) HIP_TRY(launch_pathtrace_small(s->small, s->f32.view, camf, p, (float4 *)accum_dev, (unsigned long long *)s->ray_counter.p, stream));
+    else HIP_TRY(launch_pathtrace_mega(s->f32.view, camf, p, (float4 *)accum_dev, (unsigned long long *)s->ray_counter.p, stream));
+    ss.kernel = small ? 2 : 1;
     HIP_TRY(hipEventRecord(ss.ev1, stream));
     ss.samples = (uint64_t)st->width * st->height * (uint64_t)(st->sample_end - st->sample_begin);
     ss.launches = 1; ss.pending = true;
@@ -278,11 +295,13 @@ int rtc_render_stats(const rtc_scene *scene_c, void *stream_v, rtc_stats *out) {
     StreamState &ss = it->second;
     HIP_TRY(hipEventSynchronize(ss.ev1));
     float ms = 0; HIP_TRY(hipEventElapsedTime(&ms, ss.ev0, ss.ev1));
-    unsigned long long rays = 0;
-    HIP_TRY(hipMemcpy(&rays, s->ray_counter.p, sizeof rays, hipMemcpyDeviceToHost));
+    unsigned long long cnt[4] = {0, 0, 0, 0};
+    HIP_TRY(hipMemcpy(cnt, s->ray_counter.p, sizeof cnt, hipMemcpyDeviceToHost));
+    const unsigned long long rays = cnt[0];
     std::memset(out, 0, sizeof *out);
     out->samples = ss.samples; out->rays = rays; out->kernel_ms = ms; out->total_ms = ss.total_ms > 0 ? ss.total_ms : ms;
-    out->kernel_launches = ss.launches; out->kernel_used = 1;
+    out->kernel_launches = ss.launches; out->kernel_used = ss.kernel;
+    out->wave_iterations = cnt[1];
     return RTC_OK;
 }
 

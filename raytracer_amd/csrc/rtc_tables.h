@@ -60,4 +60,23 @@ template <typename R> struct SceneT {
     int n_media;             // media among prims (stochastic hits)
     R background[3];
 };
+// ---- small-scene pack (FP32 production path for scenes of <= 64 rect/sphere leaves with solid textures) --------------
+// Everything the bounce loop touches, reshaped so that no pointer is chased per ray:
+//   SmallLeaf  : 32 B, read with ONE scalar load per leaf (the leaf index is wave-uniform)
+//                rect  : f = k, lo_a, hi_a, lo_b, hi_b   (a,b = the two in-plane axes: XY->x,y  XZ->x,z  YZ->y,z), object space
+//                sphere: f = cx, cy, cz, r*r, r           (WORLD space: rotations/translations only move the centre)
+//   SmallShade : 48 B, gathered per lane from LDS by the winning leaf: world-space outward normal (rect) or centre and
+//                1/r (sphere), resolved material (solid colour already looked up), flags
+//   SmallXform : the translate/rotate wrapper stack of a leaf collapsed to x_obj = M x_world + b (M a rotation)
+enum { RTC_SMALL_MAX_LEAVES = 64, RTC_SMALL_MAX_XFORMS = 16 };
+enum { RTC_SF_FORCED_FRONT = 1u << 8, RTC_SF_FLIP = 1u << 9, RTC_SF_SPHERE = 1u << 10 };   // SmallShade.meta bits; bits 0-7 = material type
+struct alignas(32) SmallLeaf { uint32_t meta; float f[7]; };      // meta: bits 0-1 RTC_PRIM_*, 2-3 axis, 8-15 xform id
+struct alignas(16) SmallShade { uint32_t meta; float rgb[3]; float g[4]; float param; float pad[3]; };
+struct SmallXform { float m[9]; float b[3]; };
+struct SmallScene {
+    const SmallLeaf *leaves; const SmallShade *shade; const SmallXform *xforms;
+    int n_leaves, n_xforms;
+    int any_fuzz;                                  // some metal has fuzz > 0
+};
+
 template <typename R> struct CameraT { R origin[3], llc[3], horizontal[3], vertical[3], u[3], v[3], w[3]; R lens_radius, time0, time1; };

@@ -1,0 +1,54 @@
+// Micro-benchmark (development aid): issue cost of the VALU instructions the path tracer leans on, gfx950.
+// Each kernel runs N iterations of 8 independent chains of one instruction; reports wave-instructions per cycle per SIMD
+// at a given occupancy.  hipcc --offload-arch=gfx950 -O3 valu_rates.hip -o valu_rates
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdint>
+
+#define CHK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
+constexpr int ITERS = 4096;
+
+template <int OP> __global__ void __launch_bounds__(256) k(float *out, float seed) {
+    float a[8]; uint32_t u[8]; uint64_t w[8];
+    for (int i = 0; i < 8; i++) { a[i] = seed + threadIdx.x + i; u[i] = (uint32_t)(threadIdx.x * 2654435761u + i); w[i] = u[i]; }
+    for (int it = 0; it < ITERS; ++it) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            if (OP == 0) a[i] = __builtin_fmaf(a[i], 1.0001f, 0.5f);
+            if (OP == 1) a[i] = __builtin_amdgcn_rcpf(a[i]);
+            if (OP == 2) a[i] = __builtin_amdgcn_sqrtf(a[i]);
+            if (OP == 3) a[i] = __builtin_amdgcn_sinf(a[i]);
+            if (OP == 4) { w[i] = (uint64_t)(uint32_t)w[i] * 0xD2511F53u + (w[i] >> 32); }      // v_mad_u64_u32
+            if (OP == 5) u[i] = u[i] * 0xCD9E8D57u + 12345u;                                      // v_mul_lo_u32 (+add)
+            if (OP == 6) u[i] = __umulhi(u[i], 0xCD9E8D57u) ^ u[i];                               // v_mul_hi_u32
+            if (OP == 7) u[i] = (u[i] ^ (u[i] >> 7)) + 0x9E3779B9u;                               // cheap int
+            if (OP == 8) a[i] = a[i] > 1.0f ? a[i] * 0.5f : a[i] + 0.25f;                         // cmp + cndmask-ish
+            if (OP == 9) { asm volatile("v_mul_u32_u24 %0, %0, %1" : "+v"(u[i]) : "v"(u[(i + 1) & 7])); }
+        }
+    }
+    float s = 0; for (int i = 0; i < 8; i++) s += a[i] + (float)u[i] + (float)(w[i] & 0xffff);
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+template <int OP> int run(const char *name, int instr_per_iter_per_chain) {
+    const int blocks = 256 * 8;    // 8 blocks of 256 per CU = 8 waves/SIMD if registers allow
+    float *out; CHK(hipMalloc(&out, blocks * 256 * sizeof(float)));
+    hipEvent_t e0, e1; CHK(hipEventCreate(&e0)); CHK(hipEventCreate(&e1));
+    hipLaunchKernelGGL(k<OP>, dim3(blocks), dim3(256), 0, 0, out, 1.5f);
+    CHK(hipDeviceSynchronize());
+    CHK(hipEventRecord(e0));
+    hipLaunchKernelGGL(k<OP>, dim3(blocks), dim3(256), 0, 0, out, 1.5f);
+    CHK(hipEventRecord(e1)); CHK(hipEventSynchronize(e1));
+    float ms; CHK(hipEventElapsedTime(&ms, e0, e1));
+    const double wave_instr = (double)blocks * 4 * ITERS * 8 * instr_per_iter_per_chain;
+    const double simd_cycles = ms * 1e-3 * 2.4e9 * 1024;   // 256 CU x 4 SIMD at 2.4 GHz nominal
+    printf("%-28s %8.3f ms  %6.2f cycles per wave-instruction per SIMD (nominal 2.4 GHz)\n", name, ms, simd_cycles / wave_instr);
+    CHK(hipFree(out));
+    return 0;
+}
+int main() {
+    run<0>("v_fma_f32", 1); run<1>("v_rcp_f32", 1); run<2>("v_sqrt_f32", 1); run<3>("v_sin_f32", 1);
+    run<4>("v_mad_u64_u32", 1); run<5>("v_mul_lo_u32(+add)", 2); run<6>("v_mul_hi_u32(+xor)", 2); run<7>("xor/shift/add (3)", 3);
+    run<8>("cmp+cndmask+mul+add", 4); run<9>("v_mul_u32_u24", 1);
+    return 0;
+}

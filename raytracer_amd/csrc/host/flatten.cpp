@@ -354,14 +354,16 @@ void build_small_pack(FlatScene &fs) {
         xf.push_back(x); xfd.push_back(xd); xform_of_chain[chain] = id;
         return id;
     };
-    std::vector<SmallLeaf> leaves(n); std::vector<SmallShade> shade(n);
+    // one record per source leaf, keyed for the regrouping below
+    struct Item { int key; float rect[5]; SmallSphere sph; SmallShade S; };     // key = xform * 4 + axis for rects, 1 << 20 for spheres
+    std::vector<Item> items;
     bool any_fuzz = false;
     for (size_t i = 0; i < n; i++) {
         const PrimT<double> &p = fs.prims[i];
         if (p.type != RTC_PRIM_RECT && p.type != RTC_PRIM_SPHERE) return;
         const MaterialT<double> &m = fs.materials[p.mat];
-        SmallLeaf &L = leaves[i]; SmallShade &S = shade[i];
-        std::memset(&L, 0, sizeof L); std::memset(&S, 0, sizeof S);
+        Item it; std::memset(&it, 0, sizeof it);
+        SmallShade &S = it.S;
         bool wrapped, flip;
         const int x = chain_xform(p.chain, wrapped, flip);
         if ((int)xf.size() > RTC_SMALL_MAX_XFORMS) return;
@@ -374,23 +376,51 @@ void build_small_pack(FlatScene &fs) {
             for (int k = 0; k < 3; k++) S.rgb[k] = (float)fs.textures[m.tex].v[k];
         }
         if (p.type == RTC_PRIM_RECT) {
-            L.meta = (uint32_t)RTC_PRIM_RECT | ((uint32_t)p.axis << 2) | ((uint32_t)x << 8);
+            it.key = x * 4 + p.axis;
             const int a0 = p.axis == RTC_AXIS_YZ ? 2 : 0, b0 = p.axis == RTC_AXIS_XY ? 2 : 4;   // slots of lo_a / lo_b in d[]
-            L.f[0] = (float)p.d[6]; L.f[1] = (float)p.d[a0]; L.f[2] = (float)p.d[a0 + 1]; L.f[3] = (float)p.d[b0]; L.f[4] = (float)p.d[b0 + 1];
+            it.rect[0] = (float)p.d[6]; it.rect[1] = (float)p.d[a0]; it.rect[2] = (float)p.d[b0]; it.rect[3] = (float)p.d[a0 + 1]; it.rect[4] = (float)p.d[b0 + 1];
             const int e = p.axis == RTC_AXIS_YZ ? 0 : (p.axis == RTC_AXIS_XZ ? 1 : 2);          // outward normal = +axis unit, object space
             for (int k = 0; k < 3; k++) S.g[k] = (float)M[3 * e + k];                           // world normal = M^T e  (row e of M)
         } else {
+            it.key = 1 << 20;
             // world-space centre: c_w = M^T (c_obj - b)
             const double c[3] = {p.d[0] - b[0], p.d[1] - b[1], p.d[2] - b[2]};
             double cw[3]; for (int k = 0; k < 3; k++) cw[k] = M[k] * c[0] + M[3 + k] * c[1] + M[6 + k] * c[2];
-            L.meta = (uint32_t)RTC_PRIM_SPHERE;    // xform 0: intersected in world space
-            L.f[0] = (float)cw[0]; L.f[1] = (float)cw[1]; L.f[2] = (float)cw[2]; L.f[3] = (float)(p.d[3] * p.d[3]); L.f[4] = (float)p.d[3];
+            for (int k = 0; k < 3; k++) { it.sph.c[k] = (float)cw[k]; S.g[k] = (float)cw[k]; }
+            it.sph.r2 = (float)(p.d[3] * p.d[3]);
             S.meta |= RTC_SF_SPHERE;
-            for (int k = 0; k < 3; k++) S.g[k] = (float)cw[k];
             S.g[3] = (float)(1.0 / p.d[3]);
         }
+        items.push_back(it);
     }
-    fs.small_leaves = leaves; fs.small_shade = shade; fs.small_xforms = xf; fs.small_any_fuzz = any_fuzz; fs.small_ok = true;
+    std::stable_sort(items.begin(), items.end(), [](const Item &a, const Item &b) { return a.key < b.key; });
+    std::vector<SmallPair> pairs; std::vector<SmallGroup> groups; std::vector<SmallSphere> spheres; std::vector<SmallShade> shade;
+    const float never[5] = {0.0f, HUGE_VALF, HUGE_VALF, -HUGE_VALF, -HUGE_VALF};
+    SmallShade none; std::memset(&none, 0, sizeof none);
+    size_t i = 0;
+    while (i < items.size() && items[i].key < (1 << 20)) {
+        SmallGroup g; std::memset(&g, 0, sizeof g);
+        g.xform = items[i].key / 4; g.first = (int)pairs.size();
+        for (int axis = 0; axis < 3; axis++) {                      // RTC_AXIS_XY, _XZ, _YZ in this order
+            int count = 0;
+            while (i < items.size() && items[i].key == g.xform * 4 + axis) {
+                const float *r0 = items[i].rect, *r1 = never;
+                shade.push_back(items[i].S);
+                if (i + 1 < items.size() && items[i + 1].key == items[i].key) { r1 = items[i + 1].rect; shade.push_back(items[i + 1].S); i += 2; }
+                else { shade.push_back(none); i += 1; }
+                SmallPair P; std::memset(&P, 0, sizeof P);
+                P.f[0] = r0[0]; P.f[1] = r1[0];
+                for (int k = 0; k < 4; k++) { P.f[2 + k] = r0[1 + k]; P.f[6 + k] = r1[1 + k]; }
+                pairs.push_back(P); count++;
+            }
+            (axis == 0 ? g.n_xy : axis == 1 ? g.n_xz : g.n_yz) = count;
+        }
+        groups.push_back(g);
+    }
+    for (; i < items.size(); i++) { spheres.push_back(items[i].sph); shade.push_back(items[i].S); }
+    if (shade.size() > RTC_SMALL_MAX_LEAVES) return;
+    fs.small_pairs = pairs; fs.small_groups = groups; fs.small_spheres = spheres; fs.small_shade = shade; fs.small_xforms = xf;
+    fs.small_any_fuzz = any_fuzz; fs.small_ok = true;
 }
 
 }  // namespace

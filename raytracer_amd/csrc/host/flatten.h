@@ -22,7 +22,9 @@ struct FlatScene {
     std::vector<RefStep> ref_steps; // the reference's own traversal, depth-first (FP64 check path)
     std::vector<double> ref_boxes;  // 6 doubles per RTC_STEP_NODE
     // small-scene pack (empty when the scene is not eligible: see build_small_pack in flatten.cpp)
-    std::vector<SmallLeaf> small_leaves;
+    std::vector<SmallPair> small_pairs;
+    std::vector<SmallGroup> small_groups;
+    std::vector<SmallSphere> small_spheres;
     std::vector<SmallShade> small_shade;
     std::vector<SmallXform> small_xforms;
     bool small_ok = false, small_any_fuzz = false;

@@ -5,9 +5,9 @@
 // sees the float4 accumulator once per launch.  Design, in the order the profile asked for it:
 //   * one wave64 = one 8x8 pixel tile, a lane owns a pixel; a lane whose path ended starts its next sample in the same
 //     iteration (persistent regeneration), so > 90 % of the lane slots trace a ray until the tile runs dry;
-//   * intersection = a wave-uniform loop over SmallLeaf records: ONE 32-byte scalar load per leaf feeds 64 lanes, rect
-//     tests are sub/mul/2 fma/6 compares against a per-space reciprocal direction, wrapper stacks are pre-collapsed
-//     affine maps applied once per space, not once per leaf;
+//   * intersection = wave-uniform loops over runs of SmallLeaf records that share an object space and an axis: ONE
+//     64-byte scalar load feeds two rect tests for 64 lanes, a test is sub/mul/2 fma/7 compares against a per-space
+//     reciprocal direction, wrapper stacks are pre-collapsed affine maps applied once per space, not once per leaf;
 //   * the winner's shading record (world normal or centre, resolved colour, flags) is ONE 48-byte LDS gather -- the
 //     generic path chases prim -> material -> texture through three dependent global loads;
 //   * material / pdf dispatch is a switch on the record's type; lambertian sampling uses n + uniform-sphere (the same
@@ -18,6 +18,10 @@
 
 #include "device/rt_shade.hpp"
 #include "kernels.h"
+
+#ifndef RT_EXP
+#define RT_EXP 0   // development cost probes (tools/quick_bench.py with RTC_LIB); 0 in every shipped build
+#endif
 
 namespace {
 
@@ -32,43 +36,67 @@ RT_DEV f3 xform_dir(const SmallXform &x, f3 d) {
 }
 RT_DEV f3 rcp3(f3 d) { return f3mk(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z)); }
 
-// hittable_list_hit (hittable_list.c:125-143) over the packed leaves; `src` = leaf the ray starts on (rt_core.hpp:
-// sphere_leave_t explains why FP32 needs it).  Later leaves with an equal t replace earlier ones, like the reference.
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+// rect_hit (hittable.c:494-506) for the two rects of a SmallPair, ray already split into the run's normal (on, in = 1/dn)
+// and in-plane (oab, dab) parts.  All range tests fold into ONE compare: the largest violation
+//   max(lo - p, p - hi, tmin - t, t - tbest) <= 0
+// so no lane masks are combined on the (single, shared) scalar unit; packed FP32 math does both in-plane axes at once.
+// tbest starts at a large FINITE value: a t of +inf (dn == 0) then violates t - tbest, NaNs fail the compare.
+RT_DEV void small_pair(const SmallPair &P, int id0, float on, float in, v2f oab, v2f dab, float tmin, SmallHit &h) {
+    const v2f k = {P.f[0], P.f[1]};
+    const v2f t = (k - on) * in;
+    {
+        const v2f p = oab + dab * t.x;
+        const v2f lo = {P.f[2], P.f[3]}, hi = {P.f[4], P.f[5]};
+        const v2f vl = lo - p, vh = p - hi;
+        const float viol = fmaxf(fmaxf(fmaxf(vl.x, vl.y), fmaxf(vh.x, vh.y)), fmaxf(tmin - t.x, t.x - h.t));
+        const bool hit = viol <= 0.0f;
+        h.t = hit ? t.x : h.t; h.leaf = hit ? id0 : h.leaf;
+    }
+    {
+        const v2f p = oab + dab * t.y;
+        const v2f lo = {P.f[6], P.f[7]}, hi = {P.f[8], P.f[9]};
+        const v2f vl = lo - p, vh = p - hi;
+        const float viol = fmaxf(fmaxf(fmaxf(vl.x, vl.y), fmaxf(vh.x, vh.y)), fmaxf(tmin - t.y, t.y - h.t));
+        const bool hit = viol <= 0.0f;
+        h.t = hit ? t.y : h.t; h.leaf = hit ? id0 + 1 : h.leaf;
+    }
+}
+RT_DEV void small_run(const SmallScene &ss, int first, int count, float on, float in, float oa, float da, float ob, float db, float tmin, SmallHit &h) {
+    const v2f oab = {oa, ob}, dab = {da, db};
+    for (int p = first; p < first + count; ++p) small_pair(ss.pairs[p], 2 * p, on, in, oab, dab, tmin, h);   // wave-uniform: one s_load_dwordx16
+}
+// hittable_list_hit (hittable_list.c:125-143) over the packed leaves.  `src` = leaf the ray starts on: only spheres need
+// it (rt_core.hpp sphere_leave_t); a rect left behind is rejected by tmin like in the reference.
 RT_DEV SmallHit small_closest_hit(const SmallScene &ss, f3 ow, f3 dw, float tmin, int src) {
-    SmallHit h; h.t = Mth<float>::inf(); h.leaf = -1;
+    SmallHit h; h.t = 3.0e38f; h.leaf = -1;
     const f3 invw = rcp3(dw);
-    f3 o = ow, d = dw, inv = invw;
-    int cur = 0;
-    for (int i = 0; i < ss.n_leaves; ++i) {
-        const SmallLeaf lf = ss.leaves[i];                       // wave-uniform index: one s_load_dwordx8
-        const int type = lf.meta & 3, axis = (lf.meta >> 2) & 3, xf = (lf.meta >> 8) & 0xff;
-        if (type == RTC_PRIM_RECT) {
-            if (xf != cur) {                                     // wave-uniform: enter this leaf's object space once
-                cur = xf;
-                if (xf == 0) { o = ow; d = dw; inv = invw; }
-                else { const SmallXform x = ss.xforms[xf]; o = xform_point(x, ow); d = xform_dir(x, dw); inv = rcp3(d); }
-            }
-            float on, in, oa, da, ob, db;                        // normal axis n, in-plane axes a, b (rect_hit, hittable.c:494-506)
-            if (axis == RTC_AXIS_XY) { on = o.z; in = inv.z; oa = o.x; da = d.x; ob = o.y; db = d.y; }
-            else if (axis == RTC_AXIS_XZ) { on = o.y; in = inv.y; oa = o.x; da = d.x; ob = o.z; db = d.z; }
-            else { on = o.x; in = inv.x; oa = o.y; da = d.y; ob = o.z; db = d.z; }
-            const float t = (lf.f[0] - on) * in;
-            const float a = oa + t * da, b = ob + t * db;
-            const bool hit = (t >= tmin) & (t <= h.t) & (a >= lf.f[1]) & (a <= lf.f[2]) & (b >= lf.f[3]) & (b <= lf.f[4]) & (i != src);
-            h.t = hit ? t : h.t; h.leaf = hit ? i : h.leaf;
-        } else {                                                 // sphere, world space, closest-approach form (rt_core.hpp sphere_t<float>)
-            const f3 oc = ow - f3mk(lf.f[0], lf.f[1], lf.f[2]);
-            const float inv_a = __builtin_amdgcn_rcpf(len2(dw));
+    for (int gi = 0; gi < ss.n_groups; ++gi) {
+        const SmallGroup g = ss.groups[gi];                      // wave-uniform
+        f3 o = ow, d = dw, inv = invw;
+        if (g.xform != 0) { const SmallXform x = ss.xforms[g.xform]; o = xform_point(x, ow); d = xform_dir(x, dw); inv = rcp3(d); }
+        int first = g.first;
+        small_run(ss, first, g.n_xy, o.z, inv.z, o.x, d.x, o.y, d.y, tmin, h); first += g.n_xy;
+        small_run(ss, first, g.n_xz, o.y, inv.y, o.x, d.x, o.z, d.z, tmin, h); first += g.n_xz;
+        small_run(ss, first, g.n_yz, o.x, inv.x, o.y, d.y, o.z, d.z, tmin, h);
+    }
+    if (ss.n_spheres > 0) {                                      // world space, closest-approach form (rt_core.hpp sphere_t<float>)
+        const float inv_a = __builtin_amdgcn_rcpf(len2(dw));
+        for (int s = 0; s < ss.n_spheres; ++s) {
+            const SmallSphere sp = ss.spheres[s];
+            const int id = 2 * ss.n_pairs + s;
+            const f3 oc = ow - f3mk(sp.c[0], sp.c[1], sp.c[2]);
             const float tc = -dot(oc, dw) * inv_a;
             const f3 l = oc + dw * tc;
-            const float q = (lf.f[3] - len2(l)) * inv_a;
+            const float q = (sp.r2 - len2(l)) * inv_a;
             const float sq = __builtin_amdgcn_sqrtf(fmaxf(q, 0.0f));
-            const bool from = i == src;                          // leaving this sphere: roots are {0, 2 tc}
+            const bool from = id == src;                         // leaving this sphere: roots are {0, 2 tc}
             const float t0 = from ? 2.0f * tc : tc - sq, t1 = tc + sq;
             const bool ok0 = (t0 >= tmin) & (t0 <= h.t), ok1 = (t1 >= tmin) & (t1 <= h.t) & !from;
             const float t = ok0 ? t0 : t1;
             const bool hit = (from | (q >= 0.0f)) & (ok0 | ok1);
-            h.t = hit ? t : h.t; h.leaf = hit ? i : h.leaf;
+            h.t = hit ? t : h.t; h.leaf = hit ? id : h.leaf;
         }
     }
     return h;
@@ -148,7 +176,10 @@ __global__ void __launch_bounds__(256) k_pathtrace_small(SmallScene ss, SceneT<f
         if (__builtin_amdgcn_ballot_w64(alive) == 0) break;
         ++iters;
         if (alive) {
-            const SmallHit h = small_closest_hit(ss, ro, rd, 0.001f, src);  // ray.c:56
+            SmallHit h = small_closest_hit(ss, ro, rd, 0.001f, src);  // ray.c:56
+#if RT_EXP == 1   // cost probe: intersection twice (second call perturbed so it is not CSE'd)
+            { const SmallHit h2 = small_closest_hit(ss, ro, rd, 0.001f + 1e-9f * (float)iters, src); if (h2.t < h.t) h = h2; }
+#endif
             ++nrays;
             bool done;
             if (h.leaf < 0) {
@@ -165,7 +196,10 @@ __global__ void __launch_bounds__(256) k_pathtrace_small(SmallScene ss, SceneT<f
                 if (sh.meta & RTC_SF_FORCED_FRONT) front = true;            // translate/rotate re-face an already faced normal (F11)
                 if (sh.meta & RTC_SF_FLIP) front = !front;                  // flip_face_hit, hittable.c:587-591
                 const f3 col = f3mk(sh.rgb[0], sh.rgb[1], sh.rgb[2]);
-                const Rng4 xi = rng_block(pixel, s_cur, (uint32_t)depth, P.seed_lo, P.seed_hi);
+                Rng4 xi = rng_block(pixel, s_cur, (uint32_t)depth, P.seed_lo, P.seed_hi);
+#if RT_EXP == 2   // cost probe: bounce Philox twice
+                { const Rng4 x2 = rng_block(pixel, s_cur, (uint32_t)depth + 77u, P.seed_lo, P.seed_hi); if (x2.x > 2.0f) xi = x2; }
+#endif
                 done = false;
                 f3 nd = rd;
                 if (mtype == RTC_MAT_LIGHT) {                               // material.c:229-235 (03: front face only, F15); no scatter

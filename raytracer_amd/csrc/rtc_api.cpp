@@ -100,7 +100,7 @@ struct rtc_scene {
     DeviceTables<float> f32;
     DeviceTables<double> f64;
     DevBuf ray_counter;
-    DevBuf small_leaves, small_shade, small_xforms;
+    DevBuf small_pairs, small_groups, small_spheres, small_shade, small_xforms;
     SmallScene small{};   // n_leaves == 0: not eligible
     std::map<void *, StreamState> streams;
     std::mutex mu;
@@ -138,13 +138,17 @@ rtc_scene *rtc_scene_build(const hittable_list *world, const hittable_list *ligh
     if (e == hipSuccess) e = s->ray_counter.upload(zero, sizeof zero);
     if (e == hipSuccess && s->flat.small_ok) {
         const FlatScene &fs = s->flat;
-        e = s->small_leaves.upload(fs.small_leaves.data(), fs.small_leaves.size() * sizeof(SmallLeaf));
+        e = s->small_pairs.upload(fs.small_pairs.data(), fs.small_pairs.size() * sizeof(SmallPair));
+        if (e == hipSuccess) e = s->small_groups.upload(fs.small_groups.data(), fs.small_groups.size() * sizeof(SmallGroup));
+        if (e == hipSuccess) e = s->small_spheres.upload(fs.small_spheres.data(), fs.small_spheres.size() * sizeof(SmallSphere));
         if (e == hipSuccess) e = s->small_shade.upload(fs.small_shade.data(), fs.small_shade.size() * sizeof(SmallShade));
         if (e == hipSuccess) e = s->small_xforms.upload(fs.small_xforms.data(), fs.small_xforms.size() * sizeof(SmallXform));
-        s->small.leaves = (const SmallLeaf *)s->small_leaves.p; s->small.shade = (const SmallShade *)s->small_shade.p;
-        s->small.xforms = (const SmallXform *)s->small_xforms.p;
-        s->small.n_leaves = (int)fs.small_leaves.size(); s->small.n_xforms = (int)fs.small_xforms.size();
-        s->small.any_fuzz = fs.small_any_fuzz;
+        SmallScene &m = s->small;
+        m.pairs = (const SmallPair *)s->small_pairs.p; m.groups = (const SmallGroup *)s->small_groups.p;
+        m.spheres = (const SmallSphere *)s->small_spheres.p; m.shade = (const SmallShade *)s->small_shade.p;
+        m.xforms = (const SmallXform *)s->small_xforms.p;
+        m.n_pairs = (int)fs.small_pairs.size(); m.n_groups = (int)fs.small_groups.size(); m.n_spheres = (int)fs.small_spheres.size();
+        m.n_xforms = (int)fs.small_xforms.size(); m.n_leaves = (int)fs.small_shade.size(); m.any_fuzz = fs.small_any_fuzz;
     }
     if (e != hipSuccess) { g_error = std::string("rtc_scene_build: upload failed: ") + hipGetErrorString(e); delete s; return nullptr; }
     return s;

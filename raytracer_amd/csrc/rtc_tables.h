@@ -61,21 +61,30 @@ template <typename R> struct SceneT {
     R background[3];
 };
 // ---- small-scene pack (FP32 production path for scenes of <= 64 rect/sphere leaves with solid textures) --------------
-// Everything the bounce loop touches, reshaped so that no pointer is chased per ray:
-//   SmallLeaf  : 32 B, read with ONE scalar load per leaf (the leaf index is wave-uniform)
-//                rect  : f = k, lo_a, hi_a, lo_b, hi_b   (a,b = the two in-plane axes: XY->x,y  XZ->x,z  YZ->y,z), object space
-//                sphere: f = cx, cy, cz, r*r, r           (WORLD space: rotations/translations only move the centre)
+// Everything the bounce loop touches, reshaped so that no pointer is chased per ray.  Leaf ORDER inside the pack is
+// free (the FP32 path needs the closest hit, not the reference's tie-break), so rects are grouped by object space and,
+// inside a space, by axis: the inner loops have compile-time component choices and no per-leaf branching.
+//   SmallPair  : 64 B = TWO rects of one (space, axis) run, read with ONE s_load_dwordx16 (the index is wave-uniform);
+//                f = k0 k1 | lo_a0 lo_b0 | hi_a0 hi_b0 | lo_a1 lo_b1 | hi_a1 hi_b1   (a,b = in-plane axes: XY->x,y
+//                XZ->x,z  YZ->y,z; (lo_a, lo_b) and (hi_a, hi_b) sit in aligned register pairs for packed FP32 math);
+//                a run of odd length ends with a never-hit rect (lo = +inf)
+//   SmallGroup : 32 B per object space: xform id, first pair, pairs per axis
+//   SmallSphere: 16 B, world space (rotations/translations only move the centre): cx cy cz r*r
 //   SmallShade : 48 B, gathered per lane from LDS by the winning leaf: world-space outward normal (rect) or centre and
 //                1/r (sphere), resolved material (solid colour already looked up), flags
 //   SmallXform : the translate/rotate wrapper stack of a leaf collapsed to x_obj = M x_world + b (M a rotation)
+// Leaf ids (SmallShade index, `src`): rect j of pair p -> 2p + j; sphere s -> 2 * n_pairs + s.
 enum { RTC_SMALL_MAX_LEAVES = 64, RTC_SMALL_MAX_XFORMS = 16 };
 enum { RTC_SF_FORCED_FRONT = 1u << 8, RTC_SF_FLIP = 1u << 9, RTC_SF_SPHERE = 1u << 10 };   // SmallShade.meta bits; bits 0-7 = material type
-struct alignas(32) SmallLeaf { uint32_t meta; float f[7]; };      // meta: bits 0-1 RTC_PRIM_*, 2-3 axis, 8-15 xform id
+struct alignas(64) SmallPair { float f[16]; };
+struct alignas(32) SmallGroup { int xform, first, n_xy, n_xz, n_yz, pad0, pad1, pad2; };
+struct alignas(16) SmallSphere { float c[3]; float r2; };
 struct alignas(16) SmallShade { uint32_t meta; float rgb[3]; float g[4]; float param; float pad[3]; };
 struct SmallXform { float m[9]; float b[3]; };
 struct SmallScene {
-    const SmallLeaf *leaves; const SmallShade *shade; const SmallXform *xforms;
-    int n_leaves, n_xforms;
+    const SmallPair *pairs; const SmallGroup *groups; const SmallSphere *spheres; const SmallShade *shade; const SmallXform *xforms;
+    int n_pairs, n_groups, n_spheres, n_xforms;
+    int n_leaves;                                  // 2 * n_pairs + n_spheres (padding slots included)
     int any_fuzz;                                  // some metal has fuzz > 0
 };
 

@@ -43,6 +43,19 @@ PEAK_FP32_VALU_TFLOPS = 157.3     # MI355X_MICROARCH.md: 256 CU x 4 SIMD x 32 la
 ALGO_HBM_BYTES_PER_PIXEL = 32     # float4 accumulator read + write once per launch
 
 
+def measured_traffic():
+    """HBM bytes per launch of the path-tracing kernel from the latest committed rocprofv3 --pmc passes (FETCH_SIZE x2 per
+    the gfx950 correction + WRITE_SIZE; tools/profile.sh, tools/prof_summary.py).  PMC needs its own profiler run, so
+    bench.py quotes the committed figure for the same command line; None when no profile is committed."""
+    path = os.path.join(ROOT, "profiles", "latest.json")
+    try:
+        with open(path) as f:
+            s = json.load(f)
+        return {"bytes": s["hbm_read_bytes_corrected"] + s["hbm_write_bytes"], "profile": s.get("tag"), "kernel": s.get("kernel"), "kernel_ms": s.get("avg_ms")}
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def cpu_baseline(budget_s=15.0):
     """Time the CPU side on this host (rank 0, N=1 only).  Imports the oracle: measurement only, never the product."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -54,7 +67,7 @@ def cpu_baseline(budget_s=15.0):
     threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(os.cpu_count() or 1, 16)
     _, st = o.oracle_render(WIDTH, HEIGHT, 0, 1, depth=DEPTH, rng="philox", seed=1, threads=threads)      # probe
     rate = st["samples"] / max(st["seconds"], 1e-9)
-    spp = int(max(1, min(64, budget_s * rate / (WIDTH * HEIGHT))))
+    spp = int(max(1, min(512, budget_s * rate / (WIDTH * HEIGHT))))
     _, st = o.oracle_render(WIDTH, HEIGHT, 0, spp, depth=DEPTH, rng="philox", seed=2, threads=threads)
     out["cpu_baseline"] = dict(value=st["samples"] / st["seconds"] / 1e6, unit="Msamples/s", cores=threads, kind="port",
                                mrays_per_s=st["rays"] / st["seconds"] / 1e6, seconds=round(st["seconds"], 2),
@@ -100,7 +113,7 @@ def main():
     scene, cam, view = ra.build_named_scene("cornell", aspect=WIDTH / HEIGHT)
     accum = rdist.new_accum(HEIGHT, WIDTH, dev)
     rgb8 = torch.empty((HEIGHT, WIDTH, 3), dtype=torch.uint8, device=dev)
-    kernel_ms, rays_total = [], 0
+    kernel_ms, rays_total, kernel_used, lane_fill = [], 0, [0], [0.0]
 
     def step(i, record):
         nonlocal rays_total
@@ -115,6 +128,7 @@ def main():
             st = scene.stats(stream)                             # waits for the render kernel's end event
             kernel_ms.append(st["kernel_ms"])
             rays_total += st["rays"]
+            kernel_used[0], lane_fill[0] = st["kernel_used"], st["lane_fill"]
 
     def fence():
         torch.cuda.synchronize()
@@ -145,6 +159,7 @@ def main():
         samples_all = WIDTH * HEIGHT * a.spp * world * a.steps
         rays_per_launch = rays_all / max(1, a.steps * world)
         achieved = ALGO_FLOP_PER_RAY * rays_per_launch / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
+        traffic = measured_traffic()
         line = {
             "metric": "Msamples/sec (whole node) @1080p Cornell box", "value": samples_all / elapsed / 1e6, "unit": "Msamples/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed / max(1, a.steps) * 1e3,
@@ -155,8 +170,9 @@ def main():
                        "sharding": f"samples/{world}", "collective": "reduce(sum) of float4[W*H] to rank 0" if world > 1 else "none"},
             "mrays_per_s": rays_all / elapsed / 1e6, "rays_per_sample": rays_all / samples_all,
             "roofline": {"bound": "valu", "achieved": achieved, "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP32_VALU_TFLOPS, "traffic": None,
-                         "kernel": "k_pathtrace_mega", "kernel_ms": k_ms, "rays_per_launch": rays_per_launch,
+                         "frac": achieved / PEAK_FP32_VALU_TFLOPS, "traffic": traffic["bytes"] if traffic else None,
+                         "traffic_source": traffic, "kernel": "k_pathtrace_small<0>" if kernel_used[0] == 2 else "k_pathtrace_mega",
+                         "lane_fill": lane_fill[0], "kernel_ms": k_ms, "rays_per_launch": rays_per_launch,
                          "algorithmic_flop_per_ray": ALGO_FLOP_PER_RAY,
                          "algorithmic_hbm_bytes_per_launch": ALGO_HBM_BYTES_PER_PIXEL * WIDTH * HEIGHT},
         }

@@ -4,7 +4,8 @@ d = sys.argv[1]
 out = {}
 for row in csv.DictReader(open(os.path.join(d, "trace", "trace_kernel_stats.csv"))):
     if "pathtrace" in row["Name"]:
-        out["kernel"] = row["Name"].split("(")[0].strip()
+        import re
+        out["kernel"] = re.search(r"(k_pathtrace_\w+(<\w+>)?)", row["Name"]).group(1)
         out["calls"] = int(row["Calls"]); out["avg_ms"] = float(row["AverageNs"]) / 1e6
         out["min_ms"] = float(row["MinNs"]) / 1e6; out["max_ms"] = float(row["MaxNs"]) / 1e6
 pmc = {}

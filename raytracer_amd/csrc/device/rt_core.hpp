@@ -190,62 +190,96 @@ RT_DEV HitT<R> closest_hit_ref(const SceneT<R> &sc, const RayT<R> &r, R tmin, R 
     return h;
 }
 
-// Same result from the linear BVH: any visiting order, so ties are broken explicitly -- the leaf with the
-// highest visit-order index wins, which is what the reference's left-then-right scan produces.
-template <typename R> RT_DEV bool slab(const float *lo, const float *hi, V3<R> o, V3<R> inv, R tmin, R tmax) {
-    R t0 = ((R)lo[0] - o.x) * inv.x, t1 = ((R)hi[0] - o.x) * inv.x;
-    R tn = t0 < t1 ? t0 : t1, tf = t0 < t1 ? t1 : t0;
-    t0 = ((R)lo[1] - o.y) * inv.y; t1 = ((R)hi[1] - o.y) * inv.y;
-    R a = t0 < t1 ? t0 : t1, b = t0 < t1 ? t1 : t0;
-    tn = a > tn ? a : tn; tf = b < tf ? b : tf;
-    t0 = ((R)lo[2] - o.z) * inv.z; t1 = ((R)hi[2] - o.z) * inv.z;
-    a = t0 < t1 ? t0 : t1; b = t0 < t1 ? t1 : t0;
-    tn = a > tn ? a : tn; tf = b < tf ? b : tf;
-    tn = tn > tmin ? tn : tmin; tf = tf < tmax ? tf : tmax;
-    // boxes are padded outward at build time; the extra slack covers the rounding of this test itself.
-    // NaN (0 * inf on a degenerate axis) compares false everywhere and therefore keeps the node.
-    return !(tn > tf * (R)1.0000001 + (R)1e-7);
+// ---- FP32 production BVH ------------------------------------------------------------------------------------
+// Same closest hit from the flattened BVH (rtc_tables.h BvhNode / BLeaf).  Any visiting order gives the same t; ties are
+// broken explicitly -- the leaf with the highest visit-order index (primitive id) wins, which is what the reference's
+// left-then-right scan produces.
+// Slab test of one child box: entry distance in tn; boxes are padded outward at build time and the extra slack covers
+// the rounding of this test itself.  NaN (0 * inf on a degenerate axis) compares false and therefore keeps the node.
+RT_DEV bool slab_f32(const float *lo, const float *hi, V3<float> o, V3<float> inv, float tmin, float tmax, float &tn) {
+    const float x0 = (lo[0] - o.x) * inv.x, x1 = (hi[0] - o.x) * inv.x;
+    const float y0 = (lo[1] - o.y) * inv.y, y1 = (hi[1] - o.y) * inv.y;
+    const float z0 = (lo[2] - o.z) * inv.z, z1 = (hi[2] - o.z) * inv.z;
+    tn = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), tmin));
+    const float tf = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fminf(fmaxf(z0, z1), tmax));
+    return !(tn > tf * 1.0000001f + 1e-7f);
 }
-// Traversal stacks: a private array for the FP64 check kernel, an LDS column per lane for the FP32 path tracer
-// (entry e of lane l lives at base[e * stride + l]: consecutive lanes hit consecutive banks).
-struct LocalStack {
-    int v[48]; int sp = 0;
-    RT_DEV void push(int x) { if (sp < 48) v[sp++] = x; }
-    RT_DEV bool pop(int &x) { if (sp == 0) return false; x = v[--sp]; return true; }
-};
+// Traversal stack: an LDS column per lane (entry e of lane l lives at base[e * stride + l]: consecutive lanes hit
+// consecutive banks).  A push beyond the capacity is dropped: kBvhStackCap bounds the depth the builder may produce.
 struct LdsStack {
     int *base; int stride, cap; int sp = 0;
     RT_DEV LdsStack(int *b, int s, int c) : base(b), stride(s), cap(c) {}
     RT_DEV void push(int x) { if (sp < cap) { base[sp * stride] = x; ++sp; } }
-    RT_DEV bool pop(int &x) { if (sp == 0) return false; --sp; x = base[sp * stride]; return true; }
+    RT_DEV int pop() { if (sp == 0) return RTC_BVH_EMPTY; --sp; return base[sp * stride]; }
 };
-template <typename R, typename Stack, typename MediumFn>
-RT_DEV HitT<R> closest_hit_bvh(const SceneT<R> &sc, const RayT<R> &r, R tmin, R tmax, Stack &stack, MediumFn &&medium, int src = -1) {
-    HitT<R> h; h.t = tmax; h.prim = -1;
-    const V3<R> inv = mk3<R>(Mth<R>::div((R)1, r.d.x), Mth<R>::div((R)1, r.d.y), Mth<R>::div((R)1, r.d.z));
-    int node = 0;
-    for (;;) {
-        const BvhNode nd = sc.nodes[node];
-        const bool h0 = slab<R>(nd.lo0, nd.hi0, r.o, inv, tmin, h.t), h1 = slab<R>(nd.lo1, nd.hi1, r.o, inv, tmin, h.t);
-        int next = -1;
-        // leaves first (they can only shrink h.t), then descend
-        for (int side = 0; side < 2; ++side) {
-            const bool hs = side ? h1 : h0; const int cnt = side ? nd.count1 : nd.count0; const int ch = side ? nd.child1 : nd.child0;
-            if (!hs) continue;
-            if (cnt > 0) {
-                for (int k = 0; k < cnt; ++k) {
-                    const int id = sc.leaf_prims[ch + k];
-                    const PrimT<R> &p = sc.prims[id];
-                    R t;
-                    if (p.type == RTC_PRIM_MEDIUM) { if (medium(id, h.t, t) && !(t == h.t && id < h.prim)) { h.t = t; h.prim = id; } continue; }
-                    const RayT<R> rl = p.chain ? chain_enter(sc, p.chain, r) : r;
-                    if (leaf_t(p, rl, tmin, h.t, t, id == src) && !(t == h.t && id < h.prim)) { h.t = t; h.prim = id; }
-                }
-            } else if (next < 0) next = ch;
-            else stack.push(ch);
+struct HitS { float t; int prim, slot; };
+// One BLeaf against the ray: candidate parameter in [tmin, tmax] as sphere_t / rect_t accept it.
+RT_DEV bool bleaf_t(const SceneT<float> &sc, const BLeaf &lf, const RayT<float> &r, float tmin, float tmax, bool from_here, float &t) {
+    const uint32_t type = lf.meta & 3u;
+    if (type == RTC_PRIM_RECT) {
+        if (from_here) return false;                                  // a ray cannot re-hit the plane it leaves
+        V3<float> o = r.o, d = r.d;
+        const uint32_t xf = lf.meta >> 8;
+        if (xf) {
+            const BXform x = sc.bxforms[xf];
+            o = mk3<float>(x.m[0] * r.o.x + x.m[1] * r.o.y + x.m[2] * r.o.z + x.b[0], x.m[3] * r.o.x + x.m[4] * r.o.y + x.m[5] * r.o.z + x.b[1],
+                           x.m[6] * r.o.x + x.m[7] * r.o.y + x.m[8] * r.o.z + x.b[2]);
+            d = mk3<float>(x.m[0] * r.d.x + x.m[1] * r.d.y + x.m[2] * r.d.z, x.m[3] * r.d.x + x.m[4] * r.d.y + x.m[5] * r.d.z,
+                           x.m[6] * r.d.x + x.m[7] * r.d.y + x.m[8] * r.d.z);
         }
-        if (next >= 0) { node = next; continue; }
-        if (!stack.pop(node)) break;
+        const uint32_t axis = (lf.meta >> 2) & 3u;
+        const float on = axis == RTC_AXIS_XY ? o.z : (axis == RTC_AXIS_XZ ? o.y : o.x), dn = axis == RTC_AXIS_XY ? d.z : (axis == RTC_AXIS_XZ ? d.y : d.x);
+        const float oa = axis == RTC_AXIS_YZ ? o.y : o.x, da = axis == RTC_AXIS_YZ ? d.y : d.x;
+        const float ob = axis == RTC_AXIS_XY ? o.y : o.z, db = axis == RTC_AXIS_XY ? d.y : d.z;
+        const float tt = (lf.d[0] - on) * __builtin_amdgcn_rcpf(dn);
+        if (tt < tmin || tt > tmax) return false;                      // a NaN t passes, like the reference (F20)
+        const float pa = oa + tt * da, pb = ob + tt * db;
+        if (pa < lf.d[1] || pa > lf.d[3] || pb < lf.d[2] || pb > lf.d[4]) return false;
+        t = tt; return true;
+    }
+    if (type == RTC_PRIM_SPHERE) {
+        const V3<float> c = mk3<float>(lf.d[0], lf.d[1], lf.d[2]);
+        return from_here ? sphere_leave_t(c, r, tmin, tmax, t) : sphere_t<float>(c, lf.d[3], r, tmin, tmax, t);
+    }
+    if (type == RTC_PRIM_MSPHERE) {
+        const V3<float> c = mk3<float>(lf.d[0] + lf.d[3] * r.time, lf.d[1] + lf.d[4] * r.time, lf.d[2] + lf.d[5] * r.time);
+        return from_here ? sphere_leave_t(c, r, tmin, tmax, t) : sphere_t<float>(c, lf.d[6], r, tmin, tmax, t);
+    }
+    return false;
+}
+// One loop, one step per trip: a lane either tests the two child boxes of an inner node or one leaf primitive, so lanes
+// of a wave that are in different phases of their traversal never wait for each other's inner loops.  The nearer child
+// is entered first; the farther one waits on the stack.  src_slot = leaf slot the ray starts on (-1: none).
+template <typename Stack, typename MediumFn>
+RT_DEV HitS bvh_closest_hit(const SceneT<float> &sc, const RayT<float> &r, float tmin, float tmax, Stack &stack, MediumFn &&medium, int src_slot = -1) {
+    HitS h; h.t = tmax; h.prim = -1; h.slot = -1;
+    const V3<float> inv = mk3<float>(__builtin_amdgcn_rcpf(r.d.x), __builtin_amdgcn_rcpf(r.d.y), __builtin_amdgcn_rcpf(r.d.z));
+    int cur = 0;
+    while (cur != RTC_BVH_EMPTY) {
+        if (cur >= 0) {
+            const BvhNode nd = sc.nodes[cur];
+            float n0, n1;
+            const bool h0 = slab_f32(nd.lo0, nd.hi0, r.o, inv, tmin, h.t, n0), h1 = slab_f32(nd.lo1, nd.hi1, r.o, inv, tmin, h.t, n1);
+            if (h0 && h1) {
+                const bool first0 = n0 <= n1;
+                stack.push(first0 ? nd.child1 : nd.child0);
+                cur = first0 ? nd.child0 : nd.child1;
+            } else if (h0) cur = nd.child0;
+            else if (h1) cur = nd.child1;
+            else cur = stack.pop();
+        } else {
+            const int v = ~cur, slot = v >> 3, rem = v & 7;
+            const BLeaf lf = sc.bleaves[slot];
+            float t; bool hit;
+            int id = -1;
+            if ((lf.meta & 3u) == RTC_PRIM_MEDIUM) { id = sc.leaf_prims[slot]; hit = medium(id, h.t, t); }
+            else hit = bleaf_t(sc, lf, r, tmin, h.t, slot == src_slot, t);
+            if (hit) {
+                if (id < 0) id = sc.leaf_prims[slot];
+                if (!(t == h.t && id < h.prim)) { h.t = t; h.prim = id; h.slot = slot; }
+            }
+            cur = rem ? ~(((slot + 1) << 3) | (rem - 1)) : stack.pop();
+        }
     }
     return h;
 }

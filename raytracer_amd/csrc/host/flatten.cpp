@@ -309,11 +309,79 @@ struct Builder {
         Child l = build(lo, mid), r = build(mid, hi);
         BvhNode &nd = nodes[me];
         for (int a = 0; a < 3; a++) { nd.lo0[a] = down(l.box.lo[a]); nd.hi0[a] = up(l.box.hi[a]); nd.lo1[a] = down(r.box.lo[a]); nd.hi1[a] = up(r.box.hi[a]); }
-        nd.child0 = l.child; nd.count0 = l.count; nd.child1 = r.child; nd.count1 = r.count;
+        nd.child0 = l.count ? rtc_leaf_ref(l.child, l.count) : l.child; nd.count0 = l.count;
+        nd.child1 = r.count ? rtc_leaf_ref(r.child, r.count) : r.child; nd.count1 = r.count;
         Child c; c.child = me; c.count = 0; c.box = b;
         return c;
     }
 };
+
+// Wrapper chain of a leaf collapsed to one affine map x_obj = M x_world + b (M a rotation): translate_hit subtracts the
+// offset (hittable.c:529), rotate_hit enters with rotatePoint(p, -sin, cos, axis) (hittable.c:542-545, pair choice F10).
+// wrapped = the chain holds a translate or rotate (the re-facing quirk F11 applies); flip = parity of flip_face wrappers.
+void collapse_chain(const FlatScene &fs, int chain, double M[9], double b[3], bool &wrapped, bool &flip) {
+    const ChainRange cr = fs.chains[chain];
+    wrapped = false; flip = false;
+    const double I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    std::memcpy(M, I, sizeof I); b[0] = b[1] = b[2] = 0;
+    for (int i = 0; i < cr.count; i++) {
+        const OpT<double> &o = fs.ops[cr.first + i];
+        if (o.type == RTC_OP_FLIP) { flip = !flip; continue; }
+        wrapped = true;
+        if (o.type == RTC_OP_TRANSLATE) { b[0] -= o.a; b[1] -= o.b; b[2] -= o.c; continue; }
+        const double s = -o.a, c = o.b;
+        double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+        if (o.axis == RTC_ROT_X) { R[0] = c; R[1] = -s; R[3] = s; R[4] = c; }
+        else if (o.axis == RTC_ROT_Y) { R[0] = c; R[2] = s; R[6] = -s; R[8] = c; }
+        else { R[4] = c; R[5] = -s; R[7] = s; R[8] = c; }
+        double M2[9], b2[3];
+        for (int r = 0; r < 3; r++) { for (int k = 0; k < 3; k++) M2[3 * r + k] = R[3 * r] * M[k] + R[3 * r + 1] * M[3 + k] + R[3 * r + 2] * M[6 + k]; b2[r] = R[3 * r] * b[0] + R[3 * r + 1] * b[1] + R[3 * r + 2] * b[2]; }
+        std::memcpy(M, M2, sizeof M2); std::memcpy(b, b2, sizeof b2);
+    }
+}
+// object-space point -> world space: x_w = M^T (x_obj - b)
+void to_world_point(const double M[9], const double b[3], const double p[3], double out[3]) {
+    const double c[3] = {p[0] - b[0], p[1] - b[1], p[2] - b[2]};
+    for (int k = 0; k < 3; k++) out[k] = M[k] * c[0] + M[3 + k] * c[1] + M[6 + k] * c[2];
+}
+
+// Traversal leaves of the FP32 production BVH (rtc_tables.h BLeaf), one per slot of leaf_prims.
+void build_bleaves(FlatScene &fs) {
+    fs.bleaves.clear(); fs.bxforms.clear();
+    BXform ident; for (int i = 0; i < 9; i++) ident.m[i] = (i % 4 == 0); ident.b[0] = ident.b[1] = ident.b[2] = 0;
+    fs.bxforms.push_back(ident);
+    std::map<int, int> xform_of_chain;
+    for (int id : fs.leaf_prims) {
+        const PrimT<double> &p = fs.prims[id];
+        BLeaf L; std::memset(&L, 0, sizeof L);
+        double M[9], b[3]; bool wrapped, flip;
+        collapse_chain(fs, p.chain, M, b, wrapped, flip);
+        uint32_t xform = 0;
+        if (p.type == RTC_PRIM_SPHERE) {
+            double cw[3]; to_world_point(M, b, p.d, cw);
+            for (int k = 0; k < 3; k++) L.d[k] = (float)cw[k];
+            L.d[3] = (float)p.d[3];
+        } else if (p.type == RTC_PRIM_MSPHERE) {
+            double c0[3], c1[3]; to_world_point(M, b, p.d, c0); to_world_point(M, b, p.d + 3, c1);
+            const double t0 = p.d[6], t1 = p.d[7];
+            for (int k = 0; k < 3; k++) { const double B = (c1[k] - c0[k]) / (t1 - t0); L.d[3 + k] = (float)B; L.d[k] = (float)(c0[k] - B * t0); }
+            L.d[6] = (float)p.d[8];
+        } else if (p.type == RTC_PRIM_RECT) {
+            const int a0 = p.axis == RTC_AXIS_YZ ? 2 : 0, b0 = p.axis == RTC_AXIS_XY ? 2 : 4;   // slots of lo_a / lo_b in d[]
+            L.d[0] = (float)p.d[6]; L.d[1] = (float)p.d[a0]; L.d[2] = (float)p.d[b0]; L.d[3] = (float)p.d[a0 + 1]; L.d[4] = (float)p.d[b0 + 1];
+            if (wrapped) {
+                auto it = xform_of_chain.find(p.chain);
+                if (it != xform_of_chain.end()) xform = (uint32_t)it->second;
+                else {
+                    BXform x; for (int i = 0; i < 9; i++) x.m[i] = (float)M[i]; for (int i = 0; i < 3; i++) x.b[i] = (float)b[i];
+                    xform = (uint32_t)fs.bxforms.size(); fs.bxforms.push_back(x); xform_of_chain[p.chain] = (int)xform;
+                }
+            }
+        }
+        L.meta = (uint32_t)p.type | ((uint32_t)p.axis << 2) | ((uint32_t)fs.materials[p.mat].type << 4) | (xform << 8);
+        fs.bleaves.push_back(L);
+    }
+}
 
 // Small-scene pack: eligible when every leaf is a rect or a sphere, there are at most 64 of them, and every
 // lambertian / light texture is a solid colour (so the colour can be resolved here, once, instead of per hit).
@@ -326,24 +394,8 @@ void build_small_pack(FlatScene &fs) {
     std::vector<std::array<double, 12>> xfd(1);
     { SmallXform &I = xf[0]; for (int i = 0; i < 9; i++) I.m[i] = (i % 4 == 0); I.b[0] = I.b[1] = I.b[2] = 0; xfd[0] = {1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0}; }
     auto chain_xform = [&](int chain, bool &wrapped, bool &flip) -> int {
-        const ChainRange cr = fs.chains[chain];
-        wrapped = false; flip = false;
-        double M[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, b[3] = {0, 0, 0};
-        for (int i = 0; i < cr.count; i++) {
-            const OpT<double> &o = fs.ops[cr.first + i];
-            if (o.type == RTC_OP_FLIP) { flip = !flip; continue; }
-            wrapped = true;
-            if (o.type == RTC_OP_TRANSLATE) { b[0] -= o.a; b[1] -= o.b; b[2] -= o.c; continue; }
-            // rotate_hit enters with rotatePoint(p, -sin, cos, axis) (hittable.c:542-545, pair choice F10)
-            const double s = -o.a, c = o.b;
-            double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
-            if (o.axis == RTC_ROT_X) { R[0] = c; R[1] = -s; R[3] = s; R[4] = c; }
-            else if (o.axis == RTC_ROT_Y) { R[0] = c; R[2] = s; R[6] = -s; R[8] = c; }
-            else { R[4] = c; R[5] = -s; R[7] = s; R[8] = c; }
-            double M2[9], b2[3];
-            for (int r = 0; r < 3; r++) { for (int k = 0; k < 3; k++) M2[3 * r + k] = R[3 * r] * M[k] + R[3 * r + 1] * M[3 + k] + R[3 * r + 2] * M[6 + k]; b2[r] = R[3 * r] * b[0] + R[3 * r + 1] * b[1] + R[3 * r + 2] * b[2]; }
-            std::memcpy(M, M2, sizeof M); std::memcpy(b, b2, sizeof b);
-        }
+        double M[9], b[3];
+        collapse_chain(fs, chain, M, b, wrapped, flip);
         if (!wrapped) return 0;
         auto it = xform_of_chain.find(chain);
         if (it != xform_of_chain.end()) return it->second;
@@ -457,9 +509,10 @@ bool flatten_scene(const hittable_list *world, const hittable_list *lights, cons
         if (root.count > 0) {   // degenerate: everything fell into one leaf -> wrap it in a node
             BvhNode nd; std::memset(&nd, 0, sizeof nd);
             for (int a = 0; a < 3; a++) { nd.lo0[a] = Builder::down(root.box.lo[a]); nd.hi0[a] = Builder::up(root.box.hi[a]); nd.lo1[a] = 1; nd.hi1[a] = -1; }
-            nd.child0 = root.child; nd.count0 = root.count; nd.child1 = 0; nd.count1 = 0;
+            nd.child0 = rtc_leaf_ref(root.child, root.count); nd.count0 = root.count; nd.child1 = RTC_BVH_EMPTY; nd.count1 = 0;
             out.nodes.clear(); out.nodes.push_back(nd);
         }
+        build_bleaves(out);
     }
     return true;
 }

@@ -19,6 +19,8 @@ struct FlatScene {
     std::vector<unsigned char> image_data;
     std::vector<BvhNode> nodes;
     std::vector<int> leaf_prims;
+    std::vector<BLeaf> bleaves;     // FP32 traversal leaves, one per slot of leaf_prims
+    std::vector<BXform> bxforms;    // [0] = identity
     std::vector<RefStep> ref_steps; // the reference's own traversal, depth-first (FP64 check path)
     std::vector<double> ref_boxes;  // 6 doubles per RTC_STEP_NODE
     // small-scene pack (empty when the scene is not eligible: see build_small_pack in flatten.cpp)

@@ -71,7 +71,7 @@ __global__ void __launch_bounds__(256) k_pathtrace_mega(SceneT<float> sc, Camera
     int s_next = P.s_begin, depth = 0;
     uint32_t s_cur = 0;
     bool alive = false;
-    int src = -1;                                                          // leaf the current ray starts on (-1: camera / inside a medium)
+    int src = -1;                                                          // leaf the current ray starts on (BVH: its slot, else its id; -1: camera / inside a medium)
     PathState ps;
     ps.T = f3mk(1, 1, 1); ps.L = f3mk(0, 0, 0); ps.ray.o = f3mk(0, 0, 0); ps.ray.d = f3mk(0, 0, 1); ps.ray.time = 0;
 
@@ -93,12 +93,14 @@ __global__ void __launch_bounds__(256) k_pathtrace_mega(SceneT<float> sc, Camera
         if (alive) {
             int draws = 0;
             MediumF32 medium{sc, ps.ray, 0.001f, pixel, s_cur, (uint32_t)depth, P.seed_lo, P.seed_hi, draws};
-            HitT<float> h;
+            HitT<float> h; int hit_src;                                    // hit_src: what `src` must hold for the next ray
             if (BVH) {
                 LdsStack stack(lds_stack + threadIdx.x, 256, kStackCap);
-                h = closest_hit_bvh<float>(sc, ps.ray, 0.001f, Mth<float>::inf(), stack, medium, src);   // ray.c:56
+                const HitS hs = bvh_closest_hit(sc, ps.ray, 0.001f, Mth<float>::inf(), stack, medium, src);   // ray.c:56
+                h.t = hs.t; h.prim = hs.prim; hit_src = hs.slot;
             } else {
                 h = closest_hit_linear<float>(sc, ps.ray, 0.001f, Mth<float>::inf(), medium, src);
+                hit_src = h.prim;
             }
             ++nrays;
             int status;
@@ -112,7 +114,7 @@ __global__ void __launch_bounds__(256) k_pathtrace_mega(SceneT<float> sc, Camera
                 const RecT<float> rec = resolve_hit<float>(sc, ps.ray, p, h.t, material_needs_uv(sc, m));
                 const Rng4 xi = rng_block(pixel, s_cur, (uint32_t)depth, P.seed_lo, P.seed_hi);
                 status = shade_hit(sc, ps, rec, P.integrator, P.light_weight, xi);
-                src = p.type == RTC_PRIM_MEDIUM ? -1 : h.prim;
+                src = p.type == RTC_PRIM_MEDIUM ? -1 : hit_src;
             }
             ++depth;
             if (status == RT_TERMINATE || depth >= P.max_depth) {          // ray.c:52: depth exhausted adds nothing
@@ -146,7 +148,7 @@ __global__ void __launch_bounds__(256) k_first_hit_f32(SceneT<float> sc, const f
     RayT<float> r; r.o = f3mk(a[0], a[1], a[2]); r.d = f3mk(a[3], a[4], a[5]); r.time = a[6];
     MediumF32::Never nv;
     HitT<float> h;
-    if (BVH) { LdsStack stack(lds_stack + threadIdx.x, 256, kStackCap); h = closest_hit_bvh<float>(sc, r, tmin, tmax, stack, nv); }
+    if (BVH) { LdsStack stack(lds_stack + threadIdx.x, 256, kStackCap); const HitS hs = bvh_closest_hit(sc, r, tmin, tmax, stack, nv); h.t = hs.t; h.prim = hs.prim; }
     else h = closest_hit_linear<float>(sc, r, tmin, tmax, nv);
     if (live) { prim_id[i] = h.prim; t_out[i] = h.prim >= 0 ? h.t : 0.0f; }
 }

@@ -38,7 +38,7 @@ struct DevBuf {
 };
 
 template <typename R> struct DeviceTables {
-    DevBuf prims, bprims, ops, chains, materials, textures, lights, perlin_vec, perlin_perm, images, image_data, nodes, leaf_prims, ref_steps, ref_boxes;
+    DevBuf prims, bprims, ops, chains, materials, textures, lights, perlin_vec, perlin_perm, images, image_data, nodes, leaf_prims, bleaves, bxforms, ref_steps, ref_boxes;
     SceneT<R> view;
     bool ready = false;
 };
@@ -62,6 +62,7 @@ template <typename R> hipError_t upload_tables(const FlatScene &fs, DeviceTables
     UP(prims, prims); UP(bprims, bprims); UP(ops, ops); UP(chains, fs.chains); UP(materials, mats); UP(textures, texs); UP(lights, lights);
     UP(perlin_vec, pvec); UP(perlin_perm, fs.perlin_perm); UP(images, fs.images); UP(image_data, fs.image_data); UP(nodes, fs.nodes); UP(leaf_prims, fs.leaf_prims);
     if (with_ref_steps) { UP(ref_steps, fs.ref_steps); UP(ref_boxes, fs.ref_boxes); }
+    else { UP(bleaves, fs.bleaves); UP(bxforms, fs.bxforms); }
 #undef UP
     SceneT<R> &v = dt.view;
     v.prims = (const PrimT<R> *)dt.prims.p; v.n_prims = (int)fs.prims.size();
@@ -73,6 +74,7 @@ template <typename R> hipError_t upload_tables(const FlatScene &fs, DeviceTables
     v.perlin_vec = (const R *)dt.perlin_vec.p; v.perlin_perm = (const int *)dt.perlin_perm.p;
     v.images = (const ImageDesc *)dt.images.p; v.image_data = (const unsigned char *)dt.image_data.p;
     v.nodes = (const BvhNode *)dt.nodes.p; v.leaf_prims = (const int *)dt.leaf_prims.p; v.n_nodes = (int)fs.nodes.size();
+    v.bleaves = (const BLeaf *)dt.bleaves.p; v.bxforms = (const BXform *)dt.bxforms.p;
     v.ref_steps = (const RefStep *)dt.ref_steps.p; v.ref_boxes = (const double *)dt.ref_boxes.p;
     v.n_ref_steps = with_ref_steps ? (int)fs.ref_steps.size() : 0;
     v.n_media = fs.n_media;

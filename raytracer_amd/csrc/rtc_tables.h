@@ -34,8 +34,21 @@ template <typename R> struct TextureT { int type, a, b, pad; R v[4]; };         
 template <typename R> struct LightT { int kind, axis, pad0, pad1; R d[8]; };       // entries of the `lights` list, flip_face unwrapped
 struct ImageDesc { int width, height; uint32_t offset, pad; };                     // RGB8 texels at image_data + offset
 // Two-child BVH node with both child boxes inline (one 64-byte fetch decides both children).
-// child >= 0: inner node index, count == 0;  count > 0: leaf, child = first slot in leaf_prims.
+// child >= 0: inner node index (count == 0);  child < 0: leaf reference ~((first << 3) | (count - 1)), a run of
+// `count` (1..8) consecutive slots of bleaves / leaf_prims starting at `first`.
 struct alignas(16) BvhNode { float lo0[3]; int child0; float hi0[3]; int count0; float lo1[3]; int child1; float hi1[3]; int count1; };
+enum { RTC_BVH_EMPTY = (int)0x80000000 };
+inline int rtc_leaf_ref(int first, int count) { return ~((first << 3) | (count - 1)); }
+// Traversal leaf of the FP32 production BVH: 32 bytes (two dwordx4 loads), stored in BVH leaf order (slot s of bleaves
+// is primitive leaf_prims[s]).  Rigid wrappers (translate / rotate) are applied to spheres at flatten time, so spheres
+// are always in world space; a rect under a rotation keeps its object space and names the collapsed map (bxforms).
+//   sphere : d = cx cy cz r                                (world space)
+//   msphere: d = A(3) B(3) r,  centre(time) = A + B * time  (world space; moving_sphere_center, hittable.c:455-458)
+//   rect   : d = k lo_a lo_b hi_a hi_b   (a,b = in-plane axes: XY->x,y  XZ->x,z  YZ->y,z)
+//   medium : nothing here; the record is prims[leaf_prims[s]]
+// meta: bits 0-1 RTC_PRIM_*, bits 2-3 rect axis, bits 4-6 material type (ray regrouping key), bits 8.. xform id
+struct alignas(32) BLeaf { float d[7]; uint32_t meta; };
+struct BXform { float m[9]; float b[3]; };   // x_obj = M x_world + b
 
 // One step of the REFERENCE's own traversal -- the hittable_list scan (hittable_list.c:125-143) with bvh_node_hit's
 // recursion (hittable.c:485-490) unrolled depth-first, left subtree before right.  Used by the FP64 check path only: the
@@ -56,6 +69,7 @@ template <typename R> struct SceneT {
     const R *perlin_vec;     const int *perlin_perm;   // per noise slot: 768 reals, 768 ints
     const ImageDesc *images; const unsigned char *image_data;
     const BvhNode *nodes;    const int *leaf_prims; int n_nodes;   // n_nodes == 0: brute-force loop over prims
+    const BLeaf *bleaves;    const BXform *bxforms;                // FP32 production BVH only (NULL in the FP64 tables)
     const RefStep *ref_steps; const double *ref_boxes; int n_ref_steps;   // FP64 check path; boxes = min xyz, max xyz
     int n_media;             // media among prims (stochastic hits)
     R background[3];

@@ -249,39 +249,45 @@ RT_DEV bool bleaf_t(const SceneT<float> &sc, const BLeaf &lf, const RayT<float> 
 }
 // One loop, one step per trip: a lane either tests the two child boxes of an inner node or one leaf primitive, so lanes
 // of a wave that are in different phases of their traversal never wait for each other's inner loops.  The nearer child
-// is entered first; the farther one waits on the stack.  src_slot = leaf slot the ray starts on (-1: none).
+// is entered first; the farther one waits on the stack.  The traversal is a resumable state machine (bvh_begin /
+// bvh_step) so that a persistent wave can hand a finished lane its next ray while the other lanes keep walking.
+struct BvhTrav { RayT<float> r; V3<float> inv; HitS h; int cur, src_slot; };   // src_slot = leaf slot the ray starts on (-1: none)
+RT_DEV void bvh_begin(BvhTrav &s, const RayT<float> &r, float tmax, int src_slot) {
+    s.r = r; s.inv = mk3<float>(__builtin_amdgcn_rcpf(r.d.x), __builtin_amdgcn_rcpf(r.d.y), __builtin_amdgcn_rcpf(r.d.z));
+    s.h.t = tmax; s.h.prim = -1; s.h.slot = -1; s.cur = 0; s.src_slot = src_slot;
+}
+template <typename Stack, typename MediumFn>
+RT_DEV void bvh_step(const SceneT<float> &sc, BvhTrav &s, float tmin, Stack &stack, MediumFn &&medium) {
+    if (s.cur >= 0) {
+        const BvhNode nd = sc.nodes[s.cur];
+        float n0, n1;
+        const bool h0 = slab_f32(nd.lo0, nd.hi0, s.r.o, s.inv, tmin, s.h.t, n0), h1 = slab_f32(nd.lo1, nd.hi1, s.r.o, s.inv, tmin, s.h.t, n1);
+        if (h0 && h1) {
+            const bool first0 = n0 <= n1;
+            stack.push(first0 ? nd.child1 : nd.child0);
+            s.cur = first0 ? nd.child0 : nd.child1;
+        } else if (h0) s.cur = nd.child0;
+        else if (h1) s.cur = nd.child1;
+        else s.cur = stack.pop();
+    } else {
+        const int v = ~s.cur, slot = v >> 3, rem = v & 7;
+        const BLeaf lf = sc.bleaves[slot];
+        float t; bool hit;
+        int id = -1;
+        if ((lf.meta & 3u) == RTC_PRIM_MEDIUM) { id = sc.leaf_prims[slot]; hit = medium(id, s.r, s.h.t, t); }
+        else hit = bleaf_t(sc, lf, s.r, tmin, s.h.t, slot == s.src_slot, t);
+        if (hit) {
+            if (id < 0) id = sc.leaf_prims[slot];
+            if (!(t == s.h.t && id < s.h.prim)) { s.h.t = t; s.h.prim = id; s.h.slot = slot; }
+        }
+        s.cur = rem ? ~(((slot + 1) << 3) | (rem - 1)) : stack.pop();
+    }
+}
 template <typename Stack, typename MediumFn>
 RT_DEV HitS bvh_closest_hit(const SceneT<float> &sc, const RayT<float> &r, float tmin, float tmax, Stack &stack, MediumFn &&medium, int src_slot = -1) {
-    HitS h; h.t = tmax; h.prim = -1; h.slot = -1;
-    const V3<float> inv = mk3<float>(__builtin_amdgcn_rcpf(r.d.x), __builtin_amdgcn_rcpf(r.d.y), __builtin_amdgcn_rcpf(r.d.z));
-    int cur = 0;
-    while (cur != RTC_BVH_EMPTY) {
-        if (cur >= 0) {
-            const BvhNode nd = sc.nodes[cur];
-            float n0, n1;
-            const bool h0 = slab_f32(nd.lo0, nd.hi0, r.o, inv, tmin, h.t, n0), h1 = slab_f32(nd.lo1, nd.hi1, r.o, inv, tmin, h.t, n1);
-            if (h0 && h1) {
-                const bool first0 = n0 <= n1;
-                stack.push(first0 ? nd.child1 : nd.child0);
-                cur = first0 ? nd.child0 : nd.child1;
-            } else if (h0) cur = nd.child0;
-            else if (h1) cur = nd.child1;
-            else cur = stack.pop();
-        } else {
-            const int v = ~cur, slot = v >> 3, rem = v & 7;
-            const BLeaf lf = sc.bleaves[slot];
-            float t; bool hit;
-            int id = -1;
-            if ((lf.meta & 3u) == RTC_PRIM_MEDIUM) { id = sc.leaf_prims[slot]; hit = medium(id, h.t, t); }
-            else hit = bleaf_t(sc, lf, r, tmin, h.t, slot == src_slot, t);
-            if (hit) {
-                if (id < 0) id = sc.leaf_prims[slot];
-                if (!(t == h.t && id < h.prim)) { h.t = t; h.prim = id; h.slot = slot; }
-            }
-            cur = rem ? ~(((slot + 1) << 3) | (rem - 1)) : stack.pop();
-        }
-    }
-    return h;
+    BvhTrav s; bvh_begin(s, r, tmax, src_slot);
+    while (s.cur != RTC_BVH_EMPTY) bvh_step(sc, s, tmin, stack, medium);
+    return s.h;
 }
 
 // Full hit record of the winning leaf: sphere_hit (:440-445) / rect_hit (:509-515), then the wrappers inside-out:

@@ -126,6 +126,44 @@ RT_DEV bool material_needs_uv(const SceneT<float> &sc, const MaterialT<float> &m
     return ty == RTC_TEX_IMAGE || ty == RTC_TEX_CHECKER;   // a checker may select an image texture
 }
 
+// ---- constant media in the closest-hit query (hittable.c:563-584) ----------------------------------------------------
+// The reference's constant_medium_hit is stochastic (it draws rand() for the free-flight distance), so the traversal calls
+// back into this functor for a medium leaf.  Draw k of a bounce comes from Philox block (pixel, sample, MEDIA|bounce|k/4).
+struct NoMedium32 {
+    __device__ bool operator()(int, float, float &) const { return false; }
+    __device__ bool operator()(int, const RayT<float> &, float, float &) const { return false; }
+};
+struct MediumSampler {
+    const SceneT<float> *sc; const RayT<float> *ray; float tmin; uint32_t pixel, sample, bounce, k0, k1; int draws;
+    __device__ bool operator()(int prim, float tmax, float &t_out) { return (*this)(prim, *ray, tmax, t_out); }
+    __device__ bool operator()(int prim, const RayT<float> &r, float tmax, float &t_out) {
+        const PrimT<float> &p = sc->prims[prim];
+        NoMedium32 nv;
+        const float inf = Mth<float>::inf();
+        const HitT<float> a = closest_hit_range<float>(*sc, sc->bprims, p.bnd_first, p.bnd_count, r, -inf, inf, nv);
+        if (a.prim < 0) return false;
+        // rec1.t + 0.0001 (hittable.c:566): in float the 1e-4 is absorbed once |t| > ~800 and the second query would
+        // return the first root again; keep the step at least 4 ulp so it stays a step
+        const HitT<float> b = closest_hit_range<float>(*sc, sc->bprims, p.bnd_first, p.bnd_count, r, a.t + fmaxf(0.0001f, fabsf(a.t) * 4.8e-7f), inf, nv);
+        if (b.prim < 0) return false;
+        float t1 = a.t, t2 = b.t;
+        if (t1 < tmin) t1 = tmin;
+        if (t2 > tmax) t2 = tmax;
+        if (t1 >= t2) return false;
+        if (t1 < 0) t1 = 0;
+        const RayT<float> rm = chain_enter(*sc, p.chain, r);
+        const float ray_length = length(rm.d);
+        const float inside = (t2 - t1) * ray_length;
+        const int k = draws++;
+        const Rng4 blk = rng_block(pixel, sample, RT_TAG_MEDIA | (bounce << 8) | (uint32_t)(k >> 2), k0, k1);
+        const float xi = (k & 3) == 0 ? blk.x : ((k & 3) == 1 ? blk.y : ((k & 3) == 2 ? blk.z : blk.w));
+        const float hit_distance = p.d[0] * __logf(xi);
+        if (hit_distance > inside) return false;
+        t_out = t1 + hit_distance / ray_length;
+        return true;
+    }
+};
+
 // ---- light list pdf / sampling (hittable_list.c:165-180, hittable.c:760-864) -------------------------
 RT_DEV float light_pdf_one(const LightT<float> &l, f3 o, f3 v) {
     if (l.kind == RTC_LIGHT_RECT) {                                                   // :772-788, tmin 1e-4

@@ -30,3 +30,25 @@ hipError_t launch_pathtrace_small(const SmallScene &ss, const SceneT<float> &sc,
 // Production FP32 traversal alone (brute-force loop or flattened BVH), one lane per ray; media skipped.
 hipError_t launch_first_hit_f32(const SceneT<float> &sc, const float *rays7, size_t n, float tmin, float tmax, int32_t *prim_id, float *t, hipStream_t stream);
 hipError_t launch_tonemap_u8(const float4 *accum, int n_pixels, unsigned char *rgb, hipStream_t stream);
+
+// ---- wavefront path tracer for BVH scenes (kernels_wf.hip) ----------------------------------------------------------
+// Path-slot state in HBM, SoA.  Slot s of layer k = s / slots_per_layer renders samples s_begin + k, + layers, ... of ONE
+// pixel (8x8 tiles, 64 consecutive slots per tile).
+struct WfBuffers {
+    float4 *ro, *rd, *thr, *sum;      // origin+time, direction, throughput, radiance sum of the slot
+    int4 *meta;                       // current sample, depth, leaf slot the ray starts on, pixel
+    float2 *hit;                      // t, leaf slot (int bits; -1 = miss) written by extend
+    int *active[2];                   // slot lists (ping-pong across compactions); -1 = hole
+    unsigned *counters;               // 16 words: [0] live slots, [1] compaction cursor
+    unsigned long long *stats;        // wf_stats_bytes(): [0] rays, [1] extend waves; 16 striped partial counters behind
+    int n_slots, slots_per_layer, layers;
+};
+size_t wf_bytes_per_slot();
+size_t wf_stats_bytes();
+hipError_t launch_wf_init(const CameraT<float> &cam, const RenderParams &p, const WfBuffers &b, hipStream_t stream);
+// one bounce: extend + shade over the first n_list entries of slot list `cur`
+hipError_t launch_wf_bounce(const SceneT<float> &sc, const CameraT<float> &cam, const RenderParams &p, const WfBuffers &b,
+                            int cur, unsigned n_list, hipStream_t stream);
+// list `cur` -> list `cur ^ 1` without holes
+hipError_t launch_wf_compact(const WfBuffers &b, int cur, unsigned n_list, hipStream_t stream);
+hipError_t launch_wf_finish(const RenderParams &p, const WfBuffers &b, float4 *accum, hipStream_t stream);

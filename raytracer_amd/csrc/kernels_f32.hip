@@ -15,38 +15,6 @@
 
 namespace {
 
-// constant_medium_hit (hittable.c:563-584) for the flattened boundary range of a medium leaf.
-struct MediumF32 {
-    const SceneT<float> &sc; const RayT<float> &r; float tmin; uint32_t pixel, sample, bounce, k0, k1; int &draws;
-    struct Never { __device__ bool operator()(int, float, float &) const { return false; } };
-    __device__ bool operator()(int prim, float tmax, float &t_out) const {
-        const PrimT<float> &p = sc.prims[prim];
-        Never nv;
-        const float inf = Mth<float>::inf();
-        const HitT<float> a = closest_hit_range<float>(sc, sc.bprims, p.bnd_first, p.bnd_count, r, -inf, inf, nv);
-        if (a.prim < 0) return false;
-        // rec1.t + 0.0001 (hittable.c:566): in float the 1e-4 is absorbed once |t| > ~800 and the second query would
-        // return the first root again; keep the step at least 4 ulp so it stays a step
-        const HitT<float> b = closest_hit_range<float>(sc, sc.bprims, p.bnd_first, p.bnd_count, r, a.t + fmaxf(0.0001f, fabsf(a.t) * 4.8e-7f), inf, nv);
-        if (b.prim < 0) return false;
-        float t1 = a.t, t2 = b.t;
-        if (t1 < tmin) t1 = tmin;
-        if (t2 > tmax) t2 = tmax;
-        if (t1 >= t2) return false;
-        if (t1 < 0) t1 = 0;
-        const RayT<float> rm = chain_enter(sc, p.chain, r);
-        const float ray_length = length(rm.d);
-        const float inside = (t2 - t1) * ray_length;
-        const int k = draws++;
-        const Rng4 blk = rng_block(pixel, sample, RT_TAG_MEDIA | (bounce << 8) | (uint32_t)(k >> 2), k0, k1);
-        const float xi = (k & 3) == 0 ? blk.x : ((k & 3) == 1 ? blk.y : ((k & 3) == 2 ? blk.z : blk.w));
-        const float hit_distance = p.d[0] * __logf(xi);
-        if (hit_distance > inside) return false;
-        t_out = t1 + hit_distance / ray_length;
-        return true;
-    }
-};
-
 constexpr int kStackCap = 32;
 
 template <bool BVH>
@@ -91,8 +59,7 @@ __global__ void __launch_bounds__(256) k_pathtrace_mega(SceneT<float> sc, Camera
         if (__builtin_amdgcn_ballot_w64(alive) == 0) break;                // every lane of the wave is out of samples
         ++iters;                                                           // wave-uniform: bounce iterations of this wave
         if (alive) {
-            int draws = 0;
-            MediumF32 medium{sc, ps.ray, 0.001f, pixel, s_cur, (uint32_t)depth, P.seed_lo, P.seed_hi, draws};
+            MediumSampler medium{&sc, &ps.ray, 0.001f, pixel, s_cur, (uint32_t)depth, P.seed_lo, P.seed_hi, 0};
             HitT<float> h; int hit_src;                                    // hit_src: what `src` must hold for the next ray
             if (BVH) {
                 LdsStack stack(lds_stack + threadIdx.x, 256, kStackCap);
@@ -146,7 +113,7 @@ __global__ void __launch_bounds__(256) k_first_hit_f32(SceneT<float> sc, const f
     const bool live = i < n;
     const float *a = rays7 + 7 * (live ? i : 0);
     RayT<float> r; r.o = f3mk(a[0], a[1], a[2]); r.d = f3mk(a[3], a[4], a[5]); r.time = a[6];
-    MediumF32::Never nv;
+    NoMedium32 nv;
     HitT<float> h;
     if (BVH) { LdsStack stack(lds_stack + threadIdx.x, 256, kStackCap); const HitS hs = bvh_closest_hit(sc, r, tmin, tmax, stack, nv); h.t = hs.t; h.prim = hs.prim; }
     else h = closest_hit_linear<float>(sc, r, tmin, tmax, nv);

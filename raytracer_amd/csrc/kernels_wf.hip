@@ -1,0 +1,218 @@
+// kernels_wf.hip -- wavefront path tracer for BVH scenes on gfx950 (product code).
+//
+// The persistent megakernel (kernels_f32.hip) carries the whole shading code (perlin turbulence, media, image textures)
+// in one register allocation: 154 VGPRs -> 3 waves per SIMD, and a wave waits for its slowest lane in BOTH the traversal
+// and the material switch (rocprofv3: active-lane fraction 0.20 on the Book-2 final scene).  For scenes that live in a
+// BVH the bounce loop of ray.c:50-84 is therefore split into stages that run over queues of path slots in HBM:
+//
+//   k_wf_init     every slot: first camera ray of its pixel (main.c:150-152, camera.c:46-53)
+//   k_wf_extend   closest hit for every live slot (hittable_list_hit, ray.c:56): traversal only
+//   k_wf_shade    material / pdf switch of rt_shade.hpp; ends the path or writes the scattered ray; a finished path
+//                 regenerates the slot's next sample, so a slot stays live until its pixel is out of samples
+//   k_wf_compact  every few bounces, once enough slots have died: squeezes the holes out of the slot list
+//   k_wf_finish   per pixel: accumulator += the sums of its slots (coalesced float4 read-modify-write)
+//
+// A slot owns ONE pixel and walks through its samples in a fixed order, so no atomics touch radiance and the image does
+// not depend on scheduling.  The slot list keeps its order (tile order), which keeps the state accesses coalesced.
+// Same-address atomics cost ~11 ns each on this part (measured: 32 K wave-level appends = 0.37 ms), so nothing on the
+// per-bounce path appends to a shared queue: slots die in place, and the compaction uses one atomic per 1024 entries.
+// Philox keys are the megakernel's: (pixel, sample, bounce) -- both kernels render the same estimator.
+#include <hip/hip_runtime.h>
+
+#include "device/rt_shade.hpp"
+#include "kernels.h"
+
+namespace {
+
+constexpr int kWfStackCap = 32;
+
+// live-slot counter: one atomic per wave that has something to report (a slot dies once per render)
+__device__ __forceinline__ void wave_count_sub(unsigned *__restrict__ counter, bool pred) {
+    const unsigned long long m = __builtin_amdgcn_ballot_w64(pred);
+    if (m != 0 && (threadIdx.x & 63) == __builtin_ctzll(m)) atomicSub(counter, (unsigned)__builtin_popcountll(m));
+}
+
+__device__ __forceinline__ void slot_pixel(const RenderParams &P, int ns, int slot, int &px, int &py, int &layer) {
+    layer = slot / ns;
+    const int q = slot - layer * ns, tile = q >> 6, lane = q & 63;
+    px = (tile % P.tiles_x) * 8 + (lane & 7); py = (tile / P.tiles_x) * 8 + (lane >> 3);
+}
+
+// main.c:150-152 + camera.c:46-53 for sample s of a pixel (same Philox blocks as the megakernels)
+__device__ __forceinline__ RayT<float> primary_ray(const CameraT<float> &cam, const RenderParams &P, uint32_t pixel, int px, int py, uint32_t s) {
+    const Rng4 c = rng_block(pixel, s, RT_TAG_CAMERA, P.seed_lo, P.seed_hi);
+    const float u = ((float)px + c.x) / (float)(P.width - 1), v = ((float)py + c.y) / (float)(P.height - 1);
+    float dx = 0.0f, dy = 0.0f, tm = cam.time0;
+    if (cam.lens_radius > 0.0f) { const float rr = __builtin_amdgcn_sqrtf(c.z); dx = rr * cos2pi(c.w); dy = rr * sin2pi(c.w); }
+    if (P.use_time) tm = cam.time0 + (cam.time1 - cam.time0) * rng_block(pixel, s, RT_TAG_TIME, P.seed_lo, P.seed_hi).x;
+    return camera_ray<float>(cam, u, v, dx, dy, tm);
+}
+
+__global__ void __launch_bounds__(256) k_wf_init(CameraT<float> cam, RenderParams P, WfBuffers B) {
+    const int slot = blockIdx.x * blockDim.x + threadIdx.x;
+    bool live = false;
+    if (slot < B.n_slots) {
+        int px, py, layer; slot_pixel(P, B.slots_per_layer, slot, px, py, layer);
+        B.sum[slot] = make_float4(0, 0, 0, 0);
+        const int s = P.s_begin + layer;
+        if (px < P.width && py < P.height && s < P.s_end && P.max_depth > 0) {
+            const uint32_t pixel = (uint32_t)(py * P.width + px);
+            const RayT<float> r = primary_ray(cam, P, pixel, px, py, (uint32_t)s);
+            B.ro[slot] = make_float4(r.o.x, r.o.y, r.o.z, r.time);
+            B.rd[slot] = make_float4(r.d.x, r.d.y, r.d.z, 0.0f);
+            B.thr[slot] = make_float4(1, 1, 1, 0);
+            B.meta[slot] = make_int4(s, 0, -1, (int)pixel);
+            live = true;
+        }
+        B.active[0][slot] = live ? slot : -1;
+    }
+    const int n = __syncthreads_count(live);                         // one atomic per block
+    if (threadIdx.x == 0 && n) atomicAdd(B.counters + 0, (unsigned)n);
+}
+
+// counters: [0] live slots, [1] cursor of the compaction; stats (64-bit): [0] rays, [1] extend waves with a live lane
+//
+// One lane per list entry, one ray per lane.  Two persistent variants were measured and dropped (wavefront):
+// lanes refilled from an LDS cursor once 16 of a wave idle, and lanes walking a strided private sequence with the next
+// ray prefetched into registers.  Both raised the fraction of busy lanes per traversal step (0.42 -> ~0.7 on 1M spheres)
+// and both were 35-40 % SLOWER: a refill puts a dependent slot-list -> ray-state load chain into the step loop and the
+// whole wave waits for it, while plain one-ray waves leave that latency to the other resident waves.
+__global__ void __launch_bounds__(256) k_wf_extend(SceneT<float> sc, RenderParams P, WfBuffers B, int cur, unsigned n_list) {
+    __shared__ int lds_stack[kWfStackCap * 256];
+    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int slot = i < n_list ? B.active[cur][i] : -1;
+    const bool live = slot >= 0;
+    if (live) {
+        const float4 o = B.ro[slot], d = B.rd[slot];
+        const int4 m = B.meta[slot];                                 // sample, depth, src slot, pixel
+        RayT<float> r; r.o = f3mk(o.x, o.y, o.z); r.d = f3mk(d.x, d.y, d.z); r.time = o.w;
+        MediumSampler medium{&sc, &r, 0.001f, (uint32_t)m.w, (uint32_t)m.x, (uint32_t)m.y, P.seed_lo, P.seed_hi, 0};
+        LdsStack stack(lds_stack + threadIdx.x, 256, kWfStackCap);
+        const HitS h = bvh_closest_hit(sc, r, 0.001f, Mth<float>::inf(), stack, medium, m.z);   // ray.c:56
+        B.hit[slot] = make_float2(h.t, __int_as_float(h.slot));
+    }
+    // statistics: two fire-and-forget atomics per block, striped over 8 cache lines each
+    const unsigned long long mask = __builtin_amdgcn_ballot_w64(live);
+    const int rays = __syncthreads_count(live);
+    const int waves = __syncthreads_count(mask != 0 && (threadIdx.x & 63) == 0);
+    if (threadIdx.x == 0 && rays) {
+        atomicAdd(B.stats + 8 * (1 + (blockIdx.x & 7)), (unsigned long long)rays);
+        atomicAdd(B.stats + 8 * (9 + (blockIdx.x & 7)), (unsigned long long)waves);
+    }
+}
+
+__global__ void __launch_bounds__(256) k_wf_shade(SceneT<float> sc, CameraT<float> cam, RenderParams P, WfBuffers B, int cur, unsigned n_list) {
+    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int slot = i < n_list ? B.active[cur][i] : -1;
+    bool died = false;
+    if (slot >= 0) {
+        const float4 o = B.ro[slot], d = B.rd[slot], T4 = B.thr[slot];
+        int4 m = B.meta[slot];
+        const float2 hh = B.hit[slot];
+        const int hslot = __float_as_int(hh.y);
+        PathState ps;
+        ps.ray.o = f3mk(o.x, o.y, o.z); ps.ray.d = f3mk(d.x, d.y, d.z); ps.ray.time = o.w;
+        ps.T = f3mk(T4.x, T4.y, T4.z); ps.L = f3mk(0, 0, 0);
+        const uint32_t pixel = (uint32_t)m.w;
+        int status;
+        if (hslot < 0) {                                             // ray.c:56: background (01: sky gradient)
+            const f3 bg = P.integrator == 2 ? sky_color(ps.ray.d) : f3mk(sc.background[0], sc.background[1], sc.background[2]);
+            ps.L = ps.T * bg;
+            status = RT_TERMINATE;
+        } else {
+            const PrimT<float> p = sc.prims[sc.leaf_prims[hslot]];
+            const MaterialT<float> &mat = sc.materials[p.mat];
+            const RecT<float> rec = resolve_hit<float>(sc, ps.ray, p, hh.x, material_needs_uv(sc, mat));
+            const Rng4 xi = rng_block(pixel, (uint32_t)m.x, (uint32_t)m.y, P.seed_lo, P.seed_hi);
+            status = shade_hit(sc, ps, rec, P.integrator, P.light_weight, xi);
+            m.z = p.type == RTC_PRIM_MEDIUM ? -1 : hslot;
+        }
+        ++m.y;
+        if (status == RT_TERMINATE || m.y >= P.max_depth) {          // ray.c:52: depth exhausted adds nothing
+            const bool finite = (fabsf(ps.L.x) < 3.0e38f) && (fabsf(ps.L.y) < 3.0e38f) && (fabsf(ps.L.z) < 3.0e38f);
+            if (finite && (ps.L.x != 0.0f || ps.L.y != 0.0f || ps.L.z != 0.0f)) {
+                float4 s4 = B.sum[slot]; s4.x += ps.L.x; s4.y += ps.L.y; s4.z += ps.L.z; B.sum[slot] = s4;
+            }
+            m.x += B.layers;                                         // this slot's next sample
+            if (m.x < P.s_end) {
+                int px, py, layer; slot_pixel(P, B.slots_per_layer, slot, px, py, layer);
+                ps.ray = primary_ray(cam, P, pixel, px, py, (uint32_t)m.x);
+                ps.T = f3mk(1, 1, 1); m.y = 0; m.z = -1;
+            } else died = true;
+        }
+        if (died) B.active[cur][i] = -1;                            // stays in the list as a hole until the next compaction
+        else {
+            B.ro[slot] = make_float4(ps.ray.o.x, ps.ray.o.y, ps.ray.o.z, ps.ray.time);
+            B.rd[slot] = make_float4(ps.ray.d.x, ps.ray.d.y, ps.ray.d.z, 0.0f);
+            B.thr[slot] = make_float4(ps.T.x, ps.T.y, ps.T.z, 0.0f);
+            B.meta[slot] = m;
+        }
+    }
+    wave_count_sub(B.counters + 0, died);
+}
+
+// active[cur][0..n_list) -> active[cur^1][0..live): order kept inside a block, one atomic per block
+__global__ void __launch_bounds__(1024) k_wf_compact(WfBuffers B, int cur, unsigned n_list) {
+    __shared__ unsigned wave_count[16];
+    __shared__ unsigned block_base;
+    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int slot = i < n_list ? B.active[cur][i] : -1;
+    const bool live = slot >= 0;
+    const unsigned long long mask = __builtin_amdgcn_ballot_w64(live);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) wave_count[wave] = (unsigned)__builtin_popcountll(mask);
+    __syncthreads();
+    unsigned before = 0, total = 0;
+    for (int w = 0; w < 16; ++w) { const unsigned c = wave_count[w]; before += w < wave ? c : 0u; total += c; }
+    if (threadIdx.x == 0) block_base = total ? atomicAdd(B.counters + 1, total) : 0u;
+    __syncthreads();
+    if (live) B.active[cur ^ 1][block_base + before + (unsigned)__builtin_popcountll(mask & ((1ull << lane) - 1ull))] = slot;
+}
+
+__global__ void __launch_bounds__(256) k_wf_finish(RenderParams P, WfBuffers B, float4 *__restrict__ accum, unsigned long long *__restrict__ stats) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;            // slot of layer 0
+    if (q == 0) {                                                    // fold the striped statistics
+        unsigned long long rays = 0, waves = 0;
+        for (int k = 0; k < 8; ++k) { rays += stats[8 * (1 + k)]; waves += stats[8 * (9 + k)]; }
+        stats[0] += rays; stats[1] += waves;
+    }
+    if (q >= B.slots_per_layer) return;
+    int px, py, layer; slot_pixel(P, B.slots_per_layer, q, px, py, layer);
+    if (px >= P.width || py >= P.height) return;
+    const size_t pixel = (size_t)py * P.width + px;
+    float4 a = accum[pixel];
+    for (int k = 0; k < B.layers; ++k) { const float4 s = B.sum[(size_t)k * B.slots_per_layer + q]; a.x += s.x; a.y += s.y; a.z += s.z; }
+    a.w += (float)(P.s_end - P.s_begin);
+    accum[pixel] = a;
+}
+
+}  // namespace
+
+size_t wf_bytes_per_slot() { return 4 * sizeof(float4) + sizeof(int4) + sizeof(float2) + 2 * sizeof(int); }
+size_t wf_stats_bytes() { return 17 * 8 * sizeof(unsigned long long); }   // 17 cache lines of 64 bytes
+
+hipError_t launch_wf_init(const CameraT<float> &cam, const RenderParams &p, const WfBuffers &b, hipStream_t stream) {
+    hipError_t e = hipMemsetAsync(b.counters, 0, 16 * sizeof(unsigned), stream);
+    if (e == hipSuccess) e = hipMemsetAsync(b.stats + 8, 0, 16 * 8 * sizeof(unsigned long long), stream);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_wf_init, dim3((unsigned)((b.n_slots + 255) / 256)), dim3(256), 0, stream, cam, p, b);
+    return hipGetLastError();
+}
+hipError_t launch_wf_bounce(const SceneT<float> &sc, const CameraT<float> &cam, const RenderParams &p, const WfBuffers &b,
+                            int cur, unsigned n_list, hipStream_t stream) {
+    if (n_list == 0) return hipSuccess;
+    const unsigned blocks = (n_list + 255) / 256;
+    hipLaunchKernelGGL(k_wf_extend, dim3(blocks), dim3(256), 0, stream, sc, p, b, cur, n_list);
+    hipLaunchKernelGGL(k_wf_shade, dim3(blocks), dim3(256), 0, stream, sc, cam, p, b, cur, n_list);
+    return hipGetLastError();
+}
+hipError_t launch_wf_compact(const WfBuffers &b, int cur, unsigned n_list, hipStream_t stream) {
+    hipError_t e = hipMemsetAsync(b.counters + 1, 0, sizeof(unsigned), stream);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_wf_compact, dim3((n_list + 1023) / 1024), dim3(1024), 0, stream, b, cur, n_list);
+    return hipGetLastError();
+}
+hipError_t launch_wf_finish(const RenderParams &p, const WfBuffers &b, float4 *accum, hipStream_t stream) {
+    hipLaunchKernelGGL(k_wf_finish, dim3((unsigned)((b.slots_per_layer + 255) / 256)), dim3(256), 0, stream, p, b, accum, b.stats);
+    return hipGetLastError();
+}

@@ -102,6 +102,7 @@ struct rtc_scene {
     DeviceTables<float> f32;
     DeviceTables<double> f64;
     DevBuf ray_counter;
+    DevBuf wf_pool; size_t wf_slots_cap = 0;   // wavefront path-slot state, grown on demand
     DevBuf small_pairs, small_groups, small_spheres, small_shade, small_xforms;
     SmallScene small{};   // n_leaves == 0: not eligible
     std::map<void *, StreamState> streams;
@@ -136,8 +137,8 @@ rtc_scene *rtc_scene_build(const hittable_list *world, const hittable_list *ligh
     if (!flatten_scene(world, lights, background, time0, time1, 64, s->flat)) { g_error = "flatten: " + s->flat.error; delete s; return nullptr; }
     if (hipGetDevice(&s->device) != hipSuccess) { g_error = "rtc_scene_build: no current HIP device"; delete s; return nullptr; }
     hipError_t e = upload_tables<float>(s->flat, s->f32, false);
-    unsigned long long zero[4] = {0, 0, 0, 0};   // [0] rays, [1] wave bounce-iterations
-    if (e == hipSuccess) e = s->ray_counter.upload(zero, sizeof zero);
+    std::vector<unsigned char> zero(wf_stats_bytes() + 64, 0);   // [0] rays, [1] wave bounce-iterations, striped wavefront statistics, 16 queue counters
+    if (e == hipSuccess) e = s->ray_counter.upload(zero.data(), zero.size());
     if (e == hipSuccess && s->flat.small_ok) {
         const FlatScene &fs = s->flat;
         e = s->small_pairs.upload(fs.small_pairs.data(), fs.small_pairs.size() * sizeof(SmallPair));
@@ -257,7 +258,60 @@ static int check_settings(const rtc_settings *st) {
     if (st->sample_end < st->sample_begin || st->sample_begin < 0) return fail(RTC_ERR_ARG, "bad sample range");
     if (st->max_depth < 0 || st->max_depth > 4096) return fail(RTC_ERR_ARG, "bad max_depth");
     if (st->integrator < 0 || st->integrator > 2) return fail(RTC_ERR_ARG, "integrator must be 0, 1 or 2");
-    if (st->kernel < 0 || st->kernel > 2) return fail(RTC_ERR_ARG, "kernel must be 0, 1 or 2");
+    if (st->kernel < 0 || st->kernel > 3) return fail(RTC_ERR_ARG, "kernel must be 0, 1, 2 or 3");
+    return RTC_OK;
+}
+
+// Wavefront driver (kernels_wf.hip): init, then extend + shade per bounce until no slot is live, then the accumulate.
+// The live count is read back every few bounces, so this path returns only when the work has been ENQUEUED AND RUN up to
+// the final accumulate (which is left in flight on `stream`).
+static int render_wavefront(rtc_scene *s, const CameraT<float> &camf, const RenderParams &p, const rtc_settings *st, float4 *accum, hipStream_t stream) {
+    const int spp = p.s_end - p.s_begin;
+    if (spp <= 0) return RTC_OK;
+    const long long per_layer = (long long)p.n_tiles * 64;
+    long long layers = ((1ll << 20) + per_layer - 1) / per_layer;      // aim at >= 1M slots in flight
+    if (layers > spp) layers = spp;
+    if (layers < 1) layers = 1;
+    const long long n_slots = per_layer * layers;
+    if (n_slots > (1ll << 30)) return fail(RTC_ERR_ARG, "image too large for the wavefront path");
+    const size_t per_slot = wf_bytes_per_slot();
+    if ((size_t)n_slots > s->wf_slots_cap) {
+        if (s->wf_pool.p) { HIP_TRY(hipStreamSynchronize(stream)); (void)hipFree(s->wf_pool.p); s->wf_pool.p = nullptr; s->wf_slots_cap = 0; }
+        if (hipMalloc(&s->wf_pool.p, (size_t)n_slots * per_slot + 256) != hipSuccess) { s->wf_pool.p = nullptr; return fail(RTC_ERR_NOMEM, "wavefront path-slot state does not fit in device memory"); }
+        s->wf_slots_cap = (size_t)n_slots;
+    }
+    WfBuffers b; std::memset(&b, 0, sizeof b);
+    char *base = (char *)s->wf_pool.p;
+    const size_t n = (size_t)n_slots;
+    b.ro = (float4 *)base; base += n * sizeof(float4);
+    b.rd = (float4 *)base; base += n * sizeof(float4);
+    b.thr = (float4 *)base; base += n * sizeof(float4);
+    b.sum = (float4 *)base; base += n * sizeof(float4);
+    b.meta = (int4 *)base; base += n * sizeof(int4);
+    b.hit = (float2 *)base; base += n * sizeof(float2);
+    b.active[0] = (int *)base; base += n * sizeof(int);
+    b.active[1] = (int *)base; base += n * sizeof(int);
+    b.stats = (unsigned long long *)s->ray_counter.p;
+    b.counters = (unsigned *)((char *)s->ray_counter.p + wf_stats_bytes());
+    b.n_slots = (int)n_slots; b.slots_per_layer = (int)per_layer; b.layers = (int)layers;
+    HIP_TRY(launch_wf_init(camf, p, b, stream));
+    const long long max_iterations = ((spp + layers - 1) / layers) * (long long)(p.max_depth > 0 ? p.max_depth : 1) + 1;
+    unsigned n_list = (unsigned)n_slots;
+    int cur = 0;
+    long long it = 0;
+    for (;;) {
+        unsigned live = 0;
+        HIP_TRY(hipMemcpyAsync(&live, b.counters, sizeof live, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        if (live == 0 || it >= max_iterations) break;
+        if (live < n_list - n_list / 4) {                               // a quarter of the list is holes: squeeze them out
+            HIP_TRY(launch_wf_compact(b, cur, n_list, stream));
+            cur ^= 1; n_list = live;
+        }
+        for (int k = 0; k < 8 && it < max_iterations; ++k, ++it) HIP_TRY(launch_wf_bounce(s->f32.view, camf, p, b, cur, n_list, stream));
+    }
+    HIP_TRY(launch_wf_finish(p, b, accum, stream));
+    (void)st;
     return RTC_OK;
 }
 
@@ -283,9 +337,13 @@ int rtc_render_device(const rtc_scene *scene_c, const camera *cam, const rtc_set
     const bool small = st->kernel == 2 || (st->kernel == 0 && s->small.n_leaves > 0);
     if (small && s->small.n_leaves <= 0)
         return fail(RTC_ERR_SCENE, "kernel 2 (small-scene) needs <= 64 rect/sphere leaves with solid textures and no media");
+    const bool wavefront = st->kernel == 3 || (st->kernel == 0 && !small && s->f32.view.n_nodes > 0);
+    if (wavefront && s->f32.view.n_nodes <= 0)
+        return fail(RTC_ERR_SCENE, "kernel 3 (wavefront) needs a scene that was flattened into a BVH (more than 64 leaves)");
     if (small) HIP_TRY(launch_pathtrace_small(s->small, s->f32.view, camf, p, (float4 *)accum_dev, (unsigned long long *)s->ray_counter.p, stream));
+    else if (wavefront) { rc = render_wavefront(s, camf, p, st, (float4 *)accum_dev, stream); if (rc) return rc; }
     else HIP_TRY(launch_pathtrace_mega(s->f32.view, camf, p, (float4 *)accum_dev, (unsigned long long *)s->ray_counter.p, stream));
-    ss.kernel = small ? 2 : 1;
+    ss.kernel = small ? 2 : (wavefront ? 3 : 1);
     HIP_TRY(hipEventRecord(ss.ev1, stream));
     ss.samples = (uint64_t)st->width * st->height * (uint64_t)(st->sample_end - st->sample_begin);
     ss.launches = 1; ss.pending = true;

@@ -1,22 +1,24 @@
 """Summarise a tools/profile.sh output directory: kernel stats + per-launch PMC means for the path-tracing kernel."""
 import collections, csv, glob, json, os, sys
 d = sys.argv[1]
+pat = sys.argv[2] if len(sys.argv) > 2 else "pathtrace"   # substring of the kernel name to summarise
 out = {}
 for row in csv.DictReader(open(os.path.join(d, "trace", "trace_kernel_stats.csv"))):
-    if "pathtrace" in row["Name"]:
+    if pat in row["Name"]:
         import re
-        out["kernel"] = re.search(r"(k_pathtrace_\w+(<\w+>)?)", row["Name"]).group(1)
+        out["kernel"] = re.search(r"(k_\w+(<\w+>)?)", row["Name"]).group(1)
         out["calls"] = int(row["Calls"]); out["avg_ms"] = float(row["AverageNs"]) / 1e6
         out["min_ms"] = float(row["MinNs"]) / 1e6; out["max_ms"] = float(row["MaxNs"]) / 1e6
 pmc = {}
 for f in sorted(glob.glob(os.path.join(d, "pmc_*", "*_counter_collection.csv"))):
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
-        if "pathtrace" in r["Kernel_Name"]:
+        if pat in r["Kernel_Name"]:
             agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
             out["vgpr"] = r.get("VGPR_Count"); out["sgpr"] = r.get("SGPR_Count"); out["lds"] = r.get("LDS_Block_Size")
     for k, v in agg.items():
         pmc[k] = sum(v) / len(v)
+        out["pmc_launches"] = len(v)
 out["pmc_per_launch"] = pmc
 g = pmc.get
 if g("SQ_INSTS_VALU") and g("SQ_THREAD_CYCLES_VALU"):

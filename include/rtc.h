@@ -35,7 +35,8 @@ typedef struct rtc_settings {
     uint64_t seed;               /* Philox key; the reference uses unseeded rand() (utils.h:23) */
     double mixture_light_weight; /* 0.1 (ray.c:72) */
     int kernel;                  /* 0 = auto, 1 = general megakernel (BVH, media, textures), 2 = small-scene megakernel
-                                    (<= 64 rect/sphere leaves, solid textures; RTC_ERR_SCENE when the scene is not eligible) */
+                                    (<= 64 rect/sphere leaves, solid textures), 3 = wavefront (BVH scenes: more than 64 leaves);
+                                    RTC_ERR_SCENE when the scene is not eligible for the kernel asked for */
     int reserved;
 } rtc_settings;
 
@@ -46,9 +47,9 @@ typedef struct rtc_stats {
     double   kernel_ms;          /* HIP-event time of the path-tracing kernel(s) on the launch stream */
     double   total_ms;           /* whole call incl. uploads/downloads */
     int      kernel_launches;
-    int      kernel_used;        /* 1 general megakernel, 2 small-scene megakernel */
-    uint64_t wave_iterations;    /* bounce iterations summed over waves: rays / (64 * wave_iterations) = fraction of lane
-                                    slots that traced a ray (lanes idle at the tail of their tile count against it) */
+    int      kernel_used;        /* 1 general megakernel, 2 small-scene megakernel, 3 wavefront */
+    uint64_t wave_iterations;    /* bounce iterations summed over waves (wavefront: extend waves that held a live slot):
+                                    rays / (64 * wave_iterations) = fraction of lane slots that traced a ray */
 } rtc_stats;
 
 /* Probe the current device.  0 when a gfx950-class GPU is usable.  No reference counterpart. */
@@ -73,6 +74,10 @@ int  rtc_scene_num_prims(const rtc_scene *scene);
  * geometry (sphere: c,r | moving sphere: c0,c1,t0,t1,r | rect: x0,x1,y0,y1,z0,z1,k,axis | medium: -1/density) from slot 2,
  * slot 12 = number of translate/rotate wrappers, slot 13 = flip_face parity. */
 int  rtc_scene_dump_leaves(const rtc_scene *scene, double *out16, int cap);
+/* Shape of the production BVH (inspection; no reference counterpart: the reference's tree is bvh_node_constructor's,
+ * hittable.c:163-215): out4 = inner nodes, leaf slots, levels, bytes of nodes + traversal leaves.  All 0 for a scene of
+ * at most 64 leaves (brute-force loop). */
+int  rtc_scene_bvh_info(const rtc_scene *scene, long long *out4);
 
 /* FP64, no-FMA closest hit for n host rays (7 doubles each: orig, dir, time): bit-exact replacement of
  * hittable_list_hit(world, r, tmin, tmax, &rec) (hittable_list.c:125-143).  prim_id[i] = -1 on miss.

@@ -63,7 +63,7 @@ hittable_rect_new hittable_box_new hittable_moving_sphere_new bvh_node_init hitt
 hittable_rotate_init hittable_constant_medium_init hittable_constant_medium_init_c hittable_flip_face_init
 hittable_free camera_new camera_free camera_fields rt_scene_build rt_write_png rt_write_ppm_p3""".split()
 RTC_SYMBOLS = """rtc_init rtc_last_error rtc_device_name rtc_scene_build rtc_scene_flatten_only rtc_scene_free rtc_scene_num_prims
-rtc_scene_dump_leaves rtc_first_hit_f64 rtc_first_hit_f32 rtc_primary_first_hit_f64 rtc_render_device rtc_render rtc_render_stats
+rtc_scene_dump_leaves rtc_scene_bvh_info rtc_first_hit_f64 rtc_first_hit_f32 rtc_primary_first_hit_f64 rtc_render_device rtc_render rtc_render_stats
 rtc_tonemap_u8_device rtc_tonemap_u8""".split()
 
 
@@ -128,6 +128,7 @@ def lib():
     L.rtc_scene_free.argtypes = [_P]
     L.rtc_scene_num_prims.argtypes = [_P]
     L.rtc_scene_dump_leaves.argtypes = [_P, _dp, C.c_int]
+    L.rtc_scene_bvh_info.argtypes = [_P, C.POINTER(C.c_longlong)]
     L.rtc_first_hit_f64.argtypes = [_P, _dp, C.c_size_t, C.c_double, C.c_double, _P, _dp, _dp]
     L.rtc_first_hit_f32.argtypes = [_P, _dp, C.c_size_t, C.c_double, C.c_double, _P, _P]
     L.rtc_primary_first_hit_f64.argtypes = [_P, _P, _dp, _dp, C.c_size_t, C.c_double, C.c_double, _P, _dp, _dp]
@@ -200,6 +201,11 @@ class Scene:
         out = np.zeros((max(n, 1), 16))
         lib().rtc_scene_dump_leaves(self.handle, out.ctypes.data_as(_dp), n)
         return out[:n]
+
+    def bvh_info(self):
+        out = (C.c_longlong * 4)()
+        _check(lib().rtc_scene_bvh_info(self.handle, out), "rtc_scene_bvh_info")
+        return dict(nodes=out[0], leaf_slots=out[1], depth=out[2], bytes=out[3])
 
     def first_hit(self, rays7, tmin=0.001, tmax=np.inf, want_rec=False):
         rays7 = np.ascontiguousarray(rays7, dtype=np.float64)

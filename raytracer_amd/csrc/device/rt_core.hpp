@@ -251,7 +251,15 @@ RT_DEV bool bleaf_t(const SceneT<float> &sc, const BLeaf &lf, const RayT<float> 
 // of a wave that are in different phases of their traversal never wait for each other's inner loops.  The nearer child
 // is entered first; the farther one waits on the stack.  The traversal is a resumable state machine (bvh_begin /
 // bvh_step) so that a persistent wave can hand a finished lane its next ray while the other lanes keep walking.
-struct BvhTrav { RayT<float> r; V3<float> inv; HitS h; int cur, src_slot; };   // src_slot = leaf slot the ray starts on (-1: none)
+#ifndef RT_EXP
+#define RT_EXP 0   // development probes; 0 in every shipped build
+#endif
+struct BvhTrav {
+    RayT<float> r; V3<float> inv; HitS h; int cur, src_slot;   // src_slot = leaf slot the ray starts on (-1: none)
+#if RT_EXP == 3 || RT_EXP == 4
+    unsigned n_steps = 0;                                        // probe: node (3) or leaf (4) steps of this ray
+#endif
+};
 RT_DEV void bvh_begin(BvhTrav &s, const RayT<float> &r, float tmax, int src_slot) {
     s.r = r; s.inv = mk3<float>(__builtin_amdgcn_rcpf(r.d.x), __builtin_amdgcn_rcpf(r.d.y), __builtin_amdgcn_rcpf(r.d.z));
     s.h.t = tmax; s.h.prim = -1; s.h.slot = -1; s.cur = 0; s.src_slot = src_slot;
@@ -259,6 +267,9 @@ RT_DEV void bvh_begin(BvhTrav &s, const RayT<float> &r, float tmax, int src_slot
 template <typename Stack, typename MediumFn>
 RT_DEV void bvh_step(const SceneT<float> &sc, BvhTrav &s, float tmin, Stack &stack, MediumFn &&medium) {
     if (s.cur >= 0) {
+#if RT_EXP == 3
+        ++s.n_steps;
+#endif
         const BvhNode nd = sc.nodes[s.cur];
         float n0, n1;
         const bool h0 = slab_f32(nd.lo0, nd.hi0, s.r.o, s.inv, tmin, s.h.t, n0), h1 = slab_f32(nd.lo1, nd.hi1, s.r.o, s.inv, tmin, s.h.t, n1);
@@ -270,6 +281,9 @@ RT_DEV void bvh_step(const SceneT<float> &sc, BvhTrav &s, float tmin, Stack &sta
         else if (h1) s.cur = nd.child1;
         else s.cur = stack.pop();
     } else {
+#if RT_EXP == 4
+        ++s.n_steps;
+#endif
         const int v = ~s.cur, slot = v >> 3, rem = v & 7;
         const BLeaf lf = sc.bleaves[slot];
         float t; bool hit;
@@ -287,6 +301,9 @@ template <typename Stack, typename MediumFn>
 RT_DEV HitS bvh_closest_hit(const SceneT<float> &sc, const RayT<float> &r, float tmin, float tmax, Stack &stack, MediumFn &&medium, int src_slot = -1) {
     BvhTrav s; bvh_begin(s, r, tmax, src_slot);
     while (s.cur != RTC_BVH_EMPTY) bvh_step(sc, s, tmin, stack, medium);
+#if RT_EXP == 3 || RT_EXP == 4
+    s.h.prim = (int)s.n_steps;                                   // probe builds return the step count in place of the primitive id
+#endif
     return s.h;
 }
 

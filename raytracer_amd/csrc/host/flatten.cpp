@@ -263,7 +263,9 @@ struct Builder {
         std::sort(leaf_prims.end() - (hi - lo), leaf_prims.end());
         return c;
     }
-    Child build(int lo, int hi) {
+    int max_depth = 0;
+    Child build(int lo, int hi, int depth = 1) {
+        if (depth > max_depth) max_depth = depth;
         Box b = range_box(lo, hi);
         int n = hi - lo;
         if (n <= kLeafMax) return make_leaf(lo, hi, b);
@@ -271,7 +273,9 @@ struct Builder {
         Box cb = box_empty();
         for (int i = lo; i < hi; i++) { const Box &x = boxes[idx[i]]; double c[3] = {0.5 * (x.lo[0] + x.hi[0]), 0.5 * (x.lo[1] + x.hi[1]), 0.5 * (x.lo[2] + x.hi[2])}; box_grow(cb, c); }
         int best_axis = -1, best_bin = -1; double best_cost = HUGE_VAL;
-        for (int a = 0; a < 3; a++) {
+        // past level 40 only median splits: what is left then adds at most log2(n) levels, and the traversal stack
+        // (one entry per level, RTC_BVH_MAX_DEPTH) can never overflow
+        for (int a = 0; a < 3 && depth <= 40; a++) {
             double ext = cb.hi[a] - cb.lo[a];
             if (!(ext > 0) || !std::isfinite(ext)) continue;
             Box bins[kBins]; int cnt[kBins];
@@ -306,7 +310,7 @@ struct Builder {
         }
         int me = (int)nodes.size();
         nodes.push_back(BvhNode());
-        Child l = build(lo, mid), r = build(mid, hi);
+        Child l = build(lo, mid, depth + 1), r = build(mid, hi, depth + 1);
         BvhNode &nd = nodes[me];
         for (int a = 0; a < 3; a++) { nd.lo0[a] = down(l.box.lo[a]); nd.hi0[a] = up(l.box.hi[a]); nd.lo1[a] = down(r.box.lo[a]); nd.hi1[a] = up(r.box.hi[a]); }
         nd.child0 = l.count ? rtc_leaf_ref(l.child, l.count) : l.child; nd.count0 = l.count;
@@ -512,6 +516,7 @@ bool flatten_scene(const hittable_list *world, const hittable_list *lights, cons
             nd.child0 = rtc_leaf_ref(root.child, root.count); nd.count0 = root.count; nd.child1 = RTC_BVH_EMPTY; nd.count1 = 0;
             out.nodes.clear(); out.nodes.push_back(nd);
         }
+        out.bvh_depth = b.max_depth;
         build_bleaves(out);
     }
     return true;

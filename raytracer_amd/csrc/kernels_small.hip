@@ -19,9 +19,6 @@
 #include "device/rt_shade.hpp"
 #include "kernels.h"
 
-#ifndef RT_EXP
-#define RT_EXP 0   // development cost probes (tools/quick_bench.py with RTC_LIB); 0 in every shipped build
-#endif
 
 namespace {
 

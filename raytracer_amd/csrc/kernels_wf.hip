@@ -24,7 +24,6 @@
 
 namespace {
 
-constexpr int kWfStackCap = 32;
 
 // live-slot counter: one atomic per wave that has something to report (a slot dies once per render)
 __device__ __forceinline__ void wave_count_sub(unsigned *__restrict__ counter, bool pred) {
@@ -77,24 +76,40 @@ __global__ void __launch_bounds__(256) k_wf_init(CameraT<float> cam, RenderParam
 // ray prefetched into registers.  Both raised the fraction of busy lanes per traversal step (0.42 -> ~0.7 on 1M spheres)
 // and both were 35-40 % SLOWER: a refill puts a dependent slot-list -> ray-state load chain into the step loop and the
 // whole wave waits for it, while plain one-ray waves leave that latency to the other resident waves.
-__global__ void __launch_bounds__(256) k_wf_extend(SceneT<float> sc, RenderParams P, WfBuffers B, int cur, unsigned n_list) {
-    __shared__ int lds_stack[kWfStackCap * 256];
+// 6 waves per SIMD (80 VGPRs, 4 spilled in the medium path): +3 % over the uncapped 88; 8 waves (24 spilled) is slower
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) k_wf_extend(SceneT<float> sc, RenderParams P, WfBuffers B, int cur, unsigned n_list) {
+    extern __shared__ int lds_stack[];                               // sc.bvh_depth entries per lane
     const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
     const int slot = i < n_list ? B.active[cur][i] : -1;
     const bool live = slot >= 0;
+#if RT_EXP == 3 || RT_EXP == 4
+    unsigned probe_n = 0;
+#endif
     if (live) {
         const float4 o = B.ro[slot], d = B.rd[slot];
         const int4 m = B.meta[slot];                                 // sample, depth, src slot, pixel
         RayT<float> r; r.o = f3mk(o.x, o.y, o.z); r.d = f3mk(d.x, d.y, d.z); r.time = o.w;
         MediumSampler medium{&sc, &r, 0.001f, (uint32_t)m.w, (uint32_t)m.x, (uint32_t)m.y, P.seed_lo, P.seed_hi, 0};
-        LdsStack stack(lds_stack + threadIdx.x, 256, kWfStackCap);
+        LdsStack stack(lds_stack + threadIdx.x, 256, sc.bvh_depth);
         const HitS h = bvh_closest_hit(sc, r, 0.001f, Mth<float>::inf(), stack, medium, m.z);   // ray.c:56
         B.hit[slot] = make_float2(h.t, __int_as_float(h.slot));
+#if RT_EXP == 3 || RT_EXP == 4
+        probe_n = (unsigned)h.prim;
+#endif
     }
     // statistics: two fire-and-forget atomics per block, striped over 8 cache lines each
     const unsigned long long mask = __builtin_amdgcn_ballot_w64(live);
     const int rays = __syncthreads_count(live);
+#if RT_EXP == 3 || RT_EXP == 4   // probe: total node / leaf steps instead of the wave count
+    __shared__ unsigned probe_steps;
+    if (threadIdx.x == 0) probe_steps = 0;
+    __syncthreads();
+    if (live) atomicAdd(&probe_steps, probe_n);
+    __syncthreads();
+    const int waves = (int)probe_steps;
+#else
     const int waves = __syncthreads_count(mask != 0 && (threadIdx.x & 63) == 0);
+#endif
     if (threadIdx.x == 0 && rays) {
         atomicAdd(B.stats + 8 * (1 + (blockIdx.x & 7)), (unsigned long long)rays);
         atomicAdd(B.stats + 8 * (9 + (blockIdx.x & 7)), (unsigned long long)waves);
@@ -202,7 +217,7 @@ hipError_t launch_wf_bounce(const SceneT<float> &sc, const CameraT<float> &cam, 
                             int cur, unsigned n_list, hipStream_t stream) {
     if (n_list == 0) return hipSuccess;
     const unsigned blocks = (n_list + 255) / 256;
-    hipLaunchKernelGGL(k_wf_extend, dim3(blocks), dim3(256), 0, stream, sc, p, b, cur, n_list);
+    hipLaunchKernelGGL(k_wf_extend, dim3(blocks), dim3(256), (size_t)sc.bvh_depth * 256 * sizeof(int), stream, sc, p, b, cur, n_list);
     hipLaunchKernelGGL(k_wf_shade, dim3(blocks), dim3(256), 0, stream, sc, cam, p, b, cur, n_list);
     return hipGetLastError();
 }

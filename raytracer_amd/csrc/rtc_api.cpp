@@ -77,6 +77,7 @@ template <typename R> hipError_t upload_tables(const FlatScene &fs, DeviceTables
     v.bleaves = (const BLeaf *)dt.bleaves.p; v.bxforms = (const BXform *)dt.bxforms.p;
     v.ref_steps = (const RefStep *)dt.ref_steps.p; v.ref_boxes = (const double *)dt.ref_boxes.p;
     v.n_ref_steps = with_ref_steps ? (int)fs.ref_steps.size() : 0;
+    v.bvh_depth = fs.bvh_depth < 1 ? 1 : (fs.bvh_depth > RTC_BVH_MAX_DEPTH ? RTC_BVH_MAX_DEPTH : fs.bvh_depth);
     v.n_media = fs.n_media;
     for (int i = 0; i < 3; i++) v.background[i] = (R)fs.background[i];
     dt.ready = true;
@@ -181,6 +182,14 @@ int rtc_scene_dump_leaves(const rtc_scene *scene, double *out16, int cap) {
         d[12] = fs.wrap_depth[i]; d[13] = fs.flipped[i];
     }
     return n;
+}
+
+int rtc_scene_bvh_info(const rtc_scene *scene, long long *out4) {
+    if (!scene || !out4) return fail(RTC_ERR_ARG, "rtc_scene_bvh_info: null argument");
+    const FlatScene &fs = scene->flat;
+    out4[0] = (long long)fs.nodes.size(); out4[1] = (long long)fs.bleaves.size(); out4[2] = fs.bvh_depth;
+    out4[3] = (long long)(fs.nodes.size() * sizeof(BvhNode) + fs.bleaves.size() * (sizeof(BLeaf) + sizeof(int)));
+    return RTC_OK;
 }
 
 static int ensure_f64(rtc_scene *s) {

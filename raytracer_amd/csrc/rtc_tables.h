@@ -37,7 +37,7 @@ struct ImageDesc { int width, height; uint32_t offset, pad; };                  
 // child >= 0: inner node index (count == 0);  child < 0: leaf reference ~((first << 3) | (count - 1)), a run of
 // `count` (1..8) consecutive slots of bleaves / leaf_prims starting at `first`.
 struct alignas(16) BvhNode { float lo0[3]; int child0; float hi0[3]; int count0; float lo1[3]; int child1; float hi1[3]; int count1; };
-enum { RTC_BVH_EMPTY = (int)0x80000000 };
+enum { RTC_BVH_EMPTY = (int)0x80000000, RTC_BVH_MAX_DEPTH = 64 };
 inline int rtc_leaf_ref(int first, int count) { return ~((first << 3) | (count - 1)); }
 // Traversal leaf of the FP32 production BVH: 32 bytes (two dwordx4 loads), stored in BVH leaf order (slot s of bleaves
 // is primitive leaf_prims[s]).  Rigid wrappers (translate / rotate) are applied to spheres at flatten time, so spheres
@@ -70,6 +70,7 @@ template <typename R> struct SceneT {
     const ImageDesc *images; const unsigned char *image_data;
     const BvhNode *nodes;    const int *leaf_prims; int n_nodes;   // n_nodes == 0: brute-force loop over prims
     const BLeaf *bleaves;    const BXform *bxforms;                // FP32 production BVH only (NULL in the FP64 tables)
+    int bvh_depth;           // levels of the BVH = entries the traversal stack needs
     const RefStep *ref_steps; const double *ref_boxes; int n_ref_steps;   // FP64 check path; boxes = min xyz, max xyz
     int n_media;             // media among prims (stochastic hits)
     R background[3];

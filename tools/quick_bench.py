@@ -16,5 +16,5 @@ for name, aspect, W, H, spp, arg in jobs:
         acc, st = sc.render(cam, ra.Settings(W, H, spp, view.max_depth, view.integrator, seed=rep, kernel=kern))
         if best is None or st["kernel_ms"] < best["kernel_ms"]:
             best = st
-    print(f"{name:8s} {W}x{H}x{spp}: kernel {best['kernel_ms']:8.2f} ms  {best['samples']/best['kernel_ms']*1e-3:8.1f} Msamples/s  {best['rays']/best['kernel_ms']*1e-3:8.1f} Mrays/s  rays/sample {best['rays']/best['samples']:.3f}  lane fill {best['lane_fill']:.3f}  kernel {best['kernel_used']}", flush=True)
+    print(f"{name:8s} {W}x{H}x{spp}: kernel {best['kernel_ms']:8.2f} ms  {best['samples']/best['kernel_ms']*1e-3:8.1f} Msamples/s  {best['rays']/best['kernel_ms']*1e-3:8.1f} Mrays/s  rays/sample {best['rays']/best['samples']:.3f}  lane fill {best['lane_fill']:.3f}  kernel {best['kernel_used']}  iters/ray {best['wave_iterations']/max(1,best['rays']):.3f}", flush=True)
     sc.close()

@@ -61,7 +61,7 @@ texture *texture_checker_init(texture *odd, texture *even);
 texture *texture_checker_init_c(color odd, color even);
 texture *texture_noise_init_scaled(double sc); /* builds the perlin tables with rand(), perlin.c:67-75 */
 texture *texture_noise_init(void);
-texture *texture_image_init(char *filename);   /* binary PPM (P6); NULL + message on failure like texture.c:67 */
+texture *texture_image_init(char *filename);   /* baseline JPEG or binary PPM (P6); NULL + message on failure like texture.c:67 */
 texture *texture_image_init_rgb(const unsigned char *rgb, int width, int height); /* extension: decoded pixels */
 void     textures_free_all(void);
 
@@ -121,9 +121,12 @@ typedef struct rt_scene_view {
 enum { RT_SCENE_SIMPLE = 0, RT_SCENE_CORNELL = 1, RT_SCENE_FINAL = 2, RT_SCENE_BOOK1 = 3,
        RT_SCENE_CORNELL02 = 4, RT_SCENE_CORNELL_SMOKE = 5, RT_SCENE_TWO_SPHERES = 6,
        RT_SCENE_TWO_PERLIN = 7, RT_SCENE_SIMPLE_LIGHT = 8, RT_SCENE_BOOK2_RANDOM = 9,
-       RT_SCENE_MILLION = 10 };
+       RT_SCENE_MILLION = 10, RT_SCENE_EARTH = 11, RT_SCENE_FINAL_EARTH = 12 };
 #define RT_SCENES_TYPES 1
 hittable_list *rt_scene_build(int id, int arg, hittable_list *lights, rt_scene_view *view);
+/* image file of RT_SCENE_EARTH / RT_SCENE_FINAL_EARTH (the reference hard-codes "images/earthmap.jpg", 02 main.c:159);
+ * JPEG or binary PPM; default "tests/golden/earthmap_512.ppm" relative to the working directory */
+void rt_scene_set_image_path(const char *path);
 
 /* ---- image output: 8-bit RGB rows top-to-bottom -> PNG.  flip_vertically=1 reproduces
  * stbi_flip_vertically_on_write(1) + stbi_write_png(path,w,h,3,pixels,w*3) of 03_FullTracer/main.c:170-171

@@ -27,6 +27,8 @@
 #error "scenes.c must be included/compiled before harness.c (rt_scene_view)"
 #endif
 hittable_list *rt_scene_build(int id, int arg, hittable_list *lights, rt_scene_view *view);
+void rt_scene_set_image_path(const char *path);
+void hx_set_image_path(const char *path) { rt_scene_set_image_path(path); }
 /* non-static reference functions that its headers do not declare (hittable.c:37, material.c:142) */
 void rotatePoint(vec3 original, double sin_theta, double cos_theta, rotation_axis axis, vec3 *output);
 

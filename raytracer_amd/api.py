@@ -47,7 +47,8 @@ class RtcStats(C.Structure):
 
 
 SCENES = dict(simple=0, cornell=1, final=2, book1=3, cornell02=4, cornell_smoke=5, two_spheres=6, two_perlin=7,
-              simple_light=8, book2_random=9, million=10)
+              simple_light=8, book2_random=9, million=10, earth=11, final_earth=12)
+EARTHMAP = os.path.join(os.path.dirname(_HERE), "tests", "golden", "earthmap_512.ppm")
 
 _P = C.c_void_p
 _dp = C.POINTER(C.c_double)
@@ -61,7 +62,7 @@ material_isotropic_new_from_color materials_free_all hittable_list_new hittable_
 hittable_list_index hittable_list_objects hittable_list_free hittable_lists_free_all hittable_sphere_new
 hittable_rect_new hittable_box_new hittable_moving_sphere_new bvh_node_init hittable_translate_init
 hittable_rotate_init hittable_constant_medium_init hittable_constant_medium_init_c hittable_flip_face_init
-hittable_free camera_new camera_free camera_fields rt_scene_build rt_write_png rt_write_ppm_p3""".split()
+hittable_free camera_new camera_free camera_fields rt_scene_build rt_scene_set_image_path rt_write_png rt_write_ppm_p3""".split()
 RTC_SYMBOLS = """rtc_init rtc_last_error rtc_device_name rtc_scene_build rtc_scene_flatten_only rtc_scene_free rtc_scene_num_prims
 rtc_scene_dump_leaves rtc_scene_bvh_info rtc_first_hit_f64 rtc_first_hit_f32 rtc_primary_first_hit_f64 rtc_render_device rtc_render rtc_render_stats
 rtc_tonemap_u8_device rtc_tonemap_u8""".split()
@@ -119,6 +120,8 @@ def lib():
     L.camera_free.argtypes = [_P]
     L.camera_fields.argtypes = [_P, _dp]
     L.rt_scene_build.argtypes = [C.c_int, C.c_int, _P, C.POINTER(SceneView)]
+    L.rt_scene_set_image_path.argtypes = [C.c_char_p]
+    L.rt_scene_set_image_path(EARTHMAP.encode())
     L.rt_write_png.argtypes = [C.c_char_p, C.c_int, C.c_int, _P, C.c_int]
     L.rt_write_ppm_p3.argtypes = [C.c_char_p, C.c_int, C.c_int, _P, C.c_int]
     L.rtc_last_error.restype = C.c_char_p

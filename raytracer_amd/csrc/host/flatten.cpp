@@ -290,7 +290,8 @@ struct Builder {
             for (int k = kBins - 1; k > 0; k--) { if (cnt[k]) box_merge(acc, bins[k]); c += cnt[k]; right_area[k] = c ? area(acc) : 0; right_cnt[k] = c; }
             acc = box_empty(); c = 0;
             for (int k = 0; k < kBins - 1; k++) {
-                if (cnt[k]) box_merge(acc, bins[k]); c += cnt[k];
+                if (cnt[k]) box_merge(acc, bins[k]);
+                c += cnt[k];
                 if (c == 0 || right_cnt[k + 1] == 0) continue;
                 double cost = c * area(acc) + right_cnt[k + 1] * right_area[k + 1];
                 if (cost < best_cost) { best_cost = cost; best_axis = a; best_bin = k; }

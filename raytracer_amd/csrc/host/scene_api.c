@@ -68,18 +68,28 @@ texture *texture_image_init_rgb(const unsigned char *rgb, int width, int height)
     t->pixels = (unsigned char *)malloc((size_t)width * height * 3); memcpy(t->pixels, rgb, (size_t)width * height * 3);
     return t;
 }
+/* texture.c:63-70 loads through stb_image; here: baseline JPEG (jpeg_decode.c) and binary PPM (P6, maxval 255), told apart
+ * by their magic bytes.  NULL + the reference's message on failure. */
 texture *texture_image_init(char *filename) {
-    FILE *f = fopen(filename, "rb"); int w = 0, h = 0, mx = 0;
-    if (!f || fscanf(f, "P6 %d %d %d", &w, &h, &mx) != 3 || mx != 255 || w <= 0 || h <= 0) {
-        printf("!! could not load texture image file '%s'! \n", filename); fflush(stdout); if (f) fclose(f); return NULL;
-    }
-    fgetc(f);
-    unsigned char *buf = (unsigned char *)malloc((size_t)w * h * 3);
-    size_t got = fread(buf, 1, (size_t)w * h * 3, f); fclose(f);
     texture *t = NULL;
-    if (got == (size_t)w * h * 3) t = texture_image_init_rgb(buf, w, h);
-    else { printf("!! could not load texture image file '%s'! \n", filename); fflush(stdout); }
-    free(buf); return t;
+    unsigned char *file = NULL, *rgb = NULL;
+    long size = 0; int w = 0, h = 0;
+    FILE *f = filename ? fopen(filename, "rb") : NULL;
+    if (f && fseek(f, 0, SEEK_END) == 0 && (size = ftell(f)) > 0 && fseek(f, 0, SEEK_SET) == 0 && (file = (unsigned char *)malloc((size_t)size)) != NULL
+        && fread(file, 1, (size_t)size, f) == (size_t)size) {
+        if (size > 3 && file[0] == 0xFF && file[1] == 0xD8) {
+            if (rt_jpeg_decode(file, (size_t)size, &w, &h, &rgb)) t = texture_image_init_rgb(rgb, w, h);
+        } else if (size > 8 && file[0] == 'P' && file[1] == '6') {
+            int mx = 0, used = 0;
+            if (sscanf((const char *)file, "P6 %d %d %d%n", &w, &h, &mx, &used) == 3 && mx == 255 && w > 0 && h > 0
+                && (size_t)used + 1 + (size_t)w * h * 3 <= (size_t)size)
+                t = texture_image_init_rgb(file + used + 1, w, h);
+        }
+    }
+    if (f) fclose(f);
+    free(file); free(rgb);
+    if (!t) { printf("!! could not load texture image file '%s'! \n", filename ? filename : "(null)"); fflush(stdout); }
+    return t;
 }
 void textures_free_all(void) {
     for (int i = 0; i < g_textures.n; i++) { texture *t = (texture *)g_textures.v[i]; free(t->ranvec); free(t->perm); free(t->pixels); free(t); }

@@ -7,6 +7,8 @@
 #ifndef RAYTRACER_AMD_SCENE_INTERNAL_H
 #define RAYTRACER_AMD_SCENE_INTERNAL_H
 
+#include <stddef.h>
+
 #include "raytracer.h"
 
 #ifdef __cplusplus
@@ -66,6 +68,8 @@ struct camera {
 };
 
 int rt_bounding_box(const hittable *o, double t0, double t1, rt_box *out);
+/* jpeg_decode.c: baseline JPEG -> malloc'ed RGB8, rows top to bottom; 0 on malformed / unsupported input */
+int rt_jpeg_decode(const unsigned char *data, size_t n, int *width, int *height, unsigned char **rgb_out);
 
 #ifdef __cplusplus
 }

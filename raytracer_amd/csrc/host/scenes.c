@@ -19,6 +19,7 @@
 #endif
 #include <math.h>
 #include <stdlib.h>
+#include <string.h>
 
 #ifndef RT_SCENES_TYPES
 #define RT_SCENES_TYPES
@@ -34,7 +35,7 @@ typedef struct rt_scene_view {
 enum { RT_SCENE_SIMPLE = 0, RT_SCENE_CORNELL = 1, RT_SCENE_FINAL = 2, RT_SCENE_BOOK1 = 3,
        RT_SCENE_CORNELL02 = 4, RT_SCENE_CORNELL_SMOKE = 5, RT_SCENE_TWO_SPHERES = 6,
        RT_SCENE_TWO_PERLIN = 7, RT_SCENE_SIMPLE_LIGHT = 8, RT_SCENE_BOOK2_RANDOM = 9,
-       RT_SCENE_MILLION = 10 };
+       RT_SCENE_MILLION = 10, RT_SCENE_EARTH = 11, RT_SCENE_FINAL_EARTH = 12 };
 #endif
 
 static vec3 sv3(double x, double y, double z) { vec3 v; v.x = x; v.y = y; v.z = z; return v; }
@@ -90,9 +91,14 @@ static hittable_list *scene_cornell(hittable_list *lights, rt_scene_view *v) {
 }
 #endif
 
+/* Image asset of the earth scenes.  The reference names "images/earthmap.jpg" relative to its working directory
+ * (02 main.c:159); here the path is settable, and the default is the fixture that travels with this repository. */
+static char g_rt_image_path[1024] = "tests/golden/earthmap_512.ppm";
+void rt_scene_set_image_path(const char *path) { if (path) { strncpy(g_rt_image_path, path, sizeof g_rt_image_path - 1); g_rt_image_path[sizeof g_rt_image_path - 1] = 0; } }
+
 /* 02 main.c:230-289 -- Book-2 final scene.  rand() order: 400 box heights, BVH nodes,
  * perlin tables, 3000 sphere coordinates, BVH nodes. */
-static hittable_list *scene_final(hittable_list *lights, rt_scene_view *v) {
+static hittable_list *scene_final(hittable_list *lights, rt_scene_view *v, int with_earth) {
     hittable_list *ground_boxes = hittable_list_new_no_gc(1024);
     material *ground = material_lambertian_new_from_color(sv3(0.48, 0.83, 0.53));
     for (int i = 0; i < 20; i++)
@@ -116,6 +122,11 @@ static hittable_list *scene_final(hittable_list *lights, rt_scene_view *v) {
     hittable_constant_medium_init_c(objects, boundary, 0.0001, sv3(1, 1, 1));
     texture *marble = texture_noise_init_scaled(5);
     hittable_sphere_new(objects, sv3(220, 280, 300), 80, material_lambertian_new(marble));
+    if (with_earth) { /* BASELINE config 3 names an earth-map globe; the reference's final_scene has none: book position */
+        texture *earth = texture_image_init(g_rt_image_path);
+        if (!earth) return NULL;
+        hittable_sphere_new(objects, sv3(400, 200, 400), 100, material_lambertian_new(earth));
+    }
     hittable_list *cloud = hittable_list_new_no_gc(1024);
     material *white = material_lambertian_new_from_color(sv3(0.73, 0.73, 0.73));
     for (int j = 0; j < 1000; j++) {
@@ -215,6 +226,15 @@ static hittable_list *scene_perlin(int with_light, rt_scene_view *v) {
     }
     return world;
 }
+/* 02 main.c:157-163 with the camera of its switch case 4 (:344-350) -- one globe with the earth map */
+static hittable_list *scene_earth(rt_scene_view *v) {
+    hittable_list *world = hittable_list_new(1024);
+    texture *earth = texture_image_init(g_rt_image_path);
+    if (!earth) return NULL;
+    hittable_sphere_new(world, sv3(0, 0, 0), 2, material_lambertian_new(earth));
+    view_book(v, 20, 0.0); v->integrator = 1; v->max_depth = 8;
+    return world;
+}
 /* 02 main.c:76-128 -- Book-2 random scene: checker ground, moving diffuse spheres */
 static hittable_list *scene_book2_random(rt_scene_view *v) {
     hittable_list *world = hittable_list_new(1024);
@@ -292,7 +312,9 @@ hittable_list *rt_scene_build(int id, int arg, hittable_list *lights, rt_scene_v
     case RT_SCENE_SIMPLE: return scene_simple(lights, view);
     case RT_SCENE_CORNELL: return scene_cornell(lights, view);
 #endif
-    case RT_SCENE_FINAL: return scene_final(lights, view);
+    case RT_SCENE_FINAL: return scene_final(lights, view, 0);
+    case RT_SCENE_FINAL_EARTH: return scene_final(lights, view, 1);
+    case RT_SCENE_EARTH: return scene_earth(view);
     case RT_SCENE_BOOK1: return scene_book1(view);
     case RT_SCENE_CORNELL02: return scene_cornell02(0, view);
     case RT_SCENE_CORNELL_SMOKE: return scene_cornell02(1, view);

@@ -58,7 +58,8 @@ FIRST_HIT = (("simple", 3, "ref_simple"), ("cornell", 3, "ref_cornell"), ("corne
              ("cornell_16x9", 3, "ref_cornell"), ("book1", 3, "book1"), ("final03", 3, "final"),
              ("final02", 2, "ref_final"), ("final02_scenes_c", 2, "final"), ("cornell02", 2, "ref_cornell02"),
              ("cornell02_scenes_c", 2, "cornell02"), ("cornell_smoke", 2, "cornell_smoke"), ("book2_random", 2, "book2_random"),
-             ("two_perlin", 2, "two_perlin"), ("simple_light", 2, "simple_light"), ("two_spheres", 2, "two_spheres"))
+             ("two_perlin", 2, "two_perlin"), ("simple_light", 2, "simple_light"), ("two_spheres", 2, "two_spheres"),
+             ("earth", 2, "earth"), ("final_earth", 2, "final_earth"))   # image texture: tests/golden/earthmap_512.ppm (make_earth_fixture.py)
 
 
 def task_first_hit(name):
@@ -182,11 +183,18 @@ def task_pins(which):
     elif which == "book2":
         r2.build("book2_random")
         p["book2_refloop_32x18x2"] = r2.render_refloop(32, 18, 2, 8)   # height 18 -> step 1: rows 0..15 rendered (F3)
+    elif which == "earth":                     # image texture (texture.c:136-152) through the reference's own loader
+        r2.build("earth")
+        p["earth_refloop_48x32x4"] = r2.render_refloop(48, 32, 4, 8)
+        r2.build("earth")
+        rays = r2.camera_rays(grid(24, 16), seed=21)
+        p["earth_rays"] = rays
+        p["earth_colors"] = r2.ray_colors(rays, 8, seed=33)
     np.savez_compressed(os.path.join(HERE, f"_pin_{which}.npz"), **p)
     print("pin", which, flush=True)
 
 
-PINS = ("cornell_colors", "cornell_small", "cornell_big", "simple", "final_colors", "final_small", "cornell02", "smoke", "book2")
+PINS = ("cornell_colors", "cornell_small", "cornell_big", "simple", "final_colors", "final_small", "cornell02", "smoke", "book2", "earth")
 
 
 def main():

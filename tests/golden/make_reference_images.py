@@ -28,6 +28,8 @@ JOBS = [  # name, stage, scene, aspect, W, H, spp
     ("two_perlin_128", 2, "two_perlin", 0.0, 128, 72, 512),
     ("simple_light_128", 2, "simple_light", 0.0, 128, 72, 1024),
     ("two_spheres_128", 2, "two_spheres", 0.0, 128, 72, 512),
+    ("earth_128", 2, "earth", 0.0, 128, 72, 512),
+    ("final_earth_96", 2, "final_earth", 0.0, 96, 96, 1024),
 ]
 
 

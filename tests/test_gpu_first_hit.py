@@ -22,6 +22,7 @@ FIXTURES = {
     "book1": ("book1", None, 3), "final03": ("final", None, 3), "final02": ("final", None, 2),
     "cornell02": ("cornell02", None, 2), "cornell_smoke": ("cornell_smoke", None, 2), "book2_random": ("book2_random", None, 2),
     "two_perlin": ("two_perlin", None, 2), "simple_light": ("simple_light", None, 2), "two_spheres": ("two_spheres", None, 2),
+    "earth": ("earth", None, 2), "final_earth": ("final_earth", None, 2),
 }
 EXACT_COLS = [0, 1, 2, 3, 4, 5, 6, 7, 10, 11]   # hit, t, p, normal, front_face, material type
 

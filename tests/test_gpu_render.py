@@ -33,6 +33,8 @@ TOL = {
     "two_perlin_128":    ("two_perlin",    None,   (0.0130, 0.0033, 0.005)),
     "simple_light_128":  ("simple_light",  None,   (0.0085, 0.0021, 0.005)),
     "two_spheres_128":   ("two_spheres",   None,   (0.0100, 0.0025, 0.005)),
+    "earth_128":         ("earth",         None,   (0.0040, 0.0010, 0.005)),   # image texture (texture.c:136-152)
+    "final_earth_96":    ("final_earth",   None,   (0.0320, 0.0080, 0.010)),   # BASELINE config 3 with the earth-map globe
 }
 LUMA = np.array([0.2126, 0.7152, 0.0722])
 

@@ -16,6 +16,7 @@ FIRST_HIT = {
     "book1": (3, "book1", 0), "final03": (3, "final", 0), "final02": (2, "final", 0), "final02_scenes_c": (2, "final", 0),
     "cornell02": (2, "cornell02", 0), "cornell02_scenes_c": (2, "cornell02", 0), "cornell_smoke": (2, "cornell_smoke", 0),
     "book2_random": (2, "book2_random", 0), "two_perlin": (2, "two_perlin", 0), "simple_light": (2, "simple_light", 0), "two_spheres": (2, "two_spheres", 0),
+    "earth": (2, "earth", 0), "final_earth": (2, "final_earth", 0),
 }
 
 
@@ -132,6 +133,11 @@ def test_integrator_pins(oracle_lib):
     assert np.array_equal(o.render_refloop(32, 32, 4, 8), p["smoke_refloop_32x32x4"])
     o.build("book2_random")
     assert np.array_equal(o.render_refloop(32, 18, 2, 8), p["book2_refloop_32x18x2"])
+    o.build("earth")                                                  # image texture lookup, texture.c:136-152
+    assert np.array_equal(o.render_refloop(48, 32, 4, 8), p["earth_refloop_48x32x4"])
+    o.build("earth")
+    assert np.array_equal(o.ray_colors(p["earth_rays"], 8, seed=33), p["earth_colors"])
+    assert len(np.unique(p["earth_colors"].round(3), axis=0)) > 50   # the texture really varies over the globe
 
 
 def test_cornell_256_render_is_byte_identical_to_the_reference(oracle_lib):

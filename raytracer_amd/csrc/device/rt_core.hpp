@@ -288,7 +288,10 @@ RT_DEV void bvh_step(const SceneT<float> &sc, BvhTrav &s, float tmin, Stack &sta
         const BLeaf lf = sc.bleaves[slot];
         float t; bool hit;
         int id = -1;
-        if ((lf.meta & 3u) == RTC_PRIM_MEDIUM) { id = sc.leaf_prims[slot]; hit = medium(id, s.r, s.h.t, t); }
+        if ((lf.meta & 3u) == RTC_PRIM_MEDIUM) {
+            if (lf.meta & 0x80u) hit = medium.sphere_bounded(lf.d, s.r, s.h.t, t);
+            else { id = sc.leaf_prims[slot]; hit = medium(id, s.r, s.h.t, t); }
+        }
         else hit = bleaf_t(sc, lf, s.r, tmin, s.h.t, slot == s.src_slot, t);
         if (hit) {
             if (id < 0) id = sc.leaf_prims[slot];

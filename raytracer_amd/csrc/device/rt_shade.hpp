@@ -132,9 +132,28 @@ RT_DEV bool material_needs_uv(const SceneT<float> &sc, const MaterialT<float> &m
 struct NoMedium32 {
     __device__ bool operator()(int, float, float &) const { return false; }
     __device__ bool operator()(int, const RayT<float> &, float, float &) const { return false; }
+    __device__ bool sphere_bounded(const float *, const RayT<float> &, float, float &) const { return false; }
 };
 struct MediumSampler {
     const SceneT<float> *sc; const RayT<float> *ray; float tmin; uint32_t pixel, sample, bounce, k0, k1; int draws;
+    Rng4 blk; int blk_id = -1;                                        // the Philox block the last draw came from
+    __device__ float draw() {
+        const int k = draws++;
+        if ((k >> 2) != blk_id) { blk_id = k >> 2; blk = rng_block(pixel, sample, RT_TAG_MEDIA | (bounce << 8) | (uint32_t)blk_id, k0, k1); }
+        return (k & 3) == 0 ? blk.x : ((k & 3) == 1 ? blk.y : ((k & 3) == 2 ? blk.z : blk.w));
+    }
+    // hittable.c:568-584 once the two boundary parameters are known; ray_length = |direction| in the medium's space
+    __device__ bool free_flight(float t1, float t2, float tmax, float ray_length, float neg_inv_density, float &t_out) {
+        if (t1 < tmin) t1 = tmin;
+        if (t2 > tmax) t2 = tmax;
+        if (t1 >= t2) return false;
+        if (t1 < 0) t1 = 0;
+        const float inside = (t2 - t1) * ray_length;
+        const float hit_distance = neg_inv_density * __logf(draw());
+        if (hit_distance > inside) return false;
+        t_out = t1 + hit_distance * __builtin_amdgcn_rcpf(ray_length);
+        return true;
+    }
     __device__ bool operator()(int prim, float tmax, float &t_out) { return (*this)(prim, *ray, tmax, t_out); }
     __device__ bool operator()(int prim, const RayT<float> &r, float tmax, float &t_out) {
         const PrimT<float> &p = sc->prims[prim];
@@ -146,21 +165,22 @@ struct MediumSampler {
         // return the first root again; keep the step at least 4 ulp so it stays a step
         const HitT<float> b = closest_hit_range<float>(*sc, sc->bprims, p.bnd_first, p.bnd_count, r, a.t + fmaxf(0.0001f, fabsf(a.t) * 4.8e-7f), inf, nv);
         if (b.prim < 0) return false;
-        float t1 = a.t, t2 = b.t;
-        if (t1 < tmin) t1 = tmin;
-        if (t2 > tmax) t2 = tmax;
-        if (t1 >= t2) return false;
-        if (t1 < 0) t1 = 0;
         const RayT<float> rm = chain_enter(*sc, p.chain, r);
-        const float ray_length = length(rm.d);
-        const float inside = (t2 - t1) * ray_length;
-        const int k = draws++;
-        const Rng4 blk = rng_block(pixel, sample, RT_TAG_MEDIA | (bounce << 8) | (uint32_t)(k >> 2), k0, k1);
-        const float xi = (k & 3) == 0 ? blk.x : ((k & 3) == 1 ? blk.y : ((k & 3) == 2 ? blk.z : blk.w));
-        const float hit_distance = p.d[0] * __logf(xi);
-        if (hit_distance > inside) return false;
-        t_out = t1 + hit_distance / ray_length;
-        return true;
+        return free_flight(a.t, b.t, tmax, length(rm.d), p.d[0], t_out);
+    }
+    // boundary = one sphere, d = centre, radius, neg_inv_density in world space (rtc_tables.h BLeaf): the first boundary
+    // query over (-inf, inf) returns the near root, the second one over (near + 0.0001, inf) the far root (sphere_t)
+    __device__ bool sphere_bounded(const float *d, const RayT<float> &r, float tmax, float &t_out) {
+        const f3 oc = r.o - f3mk(d[0], d[1], d[2]);
+        const float a = len2(r.d), inv_a = __builtin_amdgcn_rcpf(a);
+        const float tc = -dot(oc, r.d) * inv_a;
+        const f3 l = oc + r.d * tc;
+        const float q = (d[3] * d[3] - len2(l)) * inv_a;
+        if (q < 0.0f) return false;
+        const float sq = __builtin_amdgcn_sqrtf(q);
+        const float t1 = tc - sq, t2 = tc + sq;
+        if (t2 < t1 + fmaxf(0.0001f, fabsf(t1) * 4.8e-7f)) return false;
+        return free_flight(t1, t2, tmax, __builtin_amdgcn_sqrtf(a), d[4], t_out);
     }
 };
 

@@ -383,7 +383,19 @@ void build_bleaves(FlatScene &fs) {
                 }
             }
         }
-        L.meta = (uint32_t)p.type | ((uint32_t)p.axis << 2) | ((uint32_t)fs.materials[p.mat].type << 4) | (xform << 8);
+        uint32_t sphere_medium = 0;
+        if (p.type == RTC_PRIM_MEDIUM && p.bnd_count == 1 && fs.bprims[p.bnd_first].type == RTC_PRIM_SPHERE) {
+            // boundary = one sphere (both media of the final scene): its world-space centre and radius travel in the leaf,
+            // and the two boundary queries of constant_medium_hit become the two roots of one quadratic
+            const PrimT<double> &bp = fs.bprims[p.bnd_first];
+            double Mb[9], bb[3]; bool w2, f2;
+            collapse_chain(fs, bp.chain, Mb, bb, w2, f2);
+            double cw[3]; to_world_point(Mb, bb, bp.d, cw);
+            for (int k = 0; k < 3; k++) L.d[k] = (float)cw[k];
+            L.d[3] = (float)bp.d[3]; L.d[4] = (float)p.d[0];
+            sphere_medium = 1u << 7;
+        }
+        L.meta = (uint32_t)p.type | ((uint32_t)p.axis << 2) | ((uint32_t)fs.materials[p.mat].type << 4) | sphere_medium | (xform << 8);
         fs.bleaves.push_back(L);
     }
 }

@@ -219,7 +219,7 @@ RT_DEV bool bleaf_t(const SceneT<float> &sc, const BLeaf &lf, const RayT<float> 
     if (type == RTC_PRIM_RECT) {
         if (from_here) return false;                                  // a ray cannot re-hit the plane it leaves
         V3<float> o = r.o, d = r.d;
-        const uint32_t xf = lf.meta >> 8;
+        const uint32_t xf = lf.meta >> 12;
         if (xf) {
             const BXform x = sc.bxforms[xf];
             o = mk3<float>(x.m[0] * r.o.x + x.m[1] * r.o.y + x.m[2] * r.o.z + x.b[0], x.m[3] * r.o.x + x.m[4] * r.o.y + x.m[5] * r.o.z + x.b[1],

@@ -395,7 +395,9 @@ void build_bleaves(FlatScene &fs) {
             L.d[3] = (float)bp.d[3]; L.d[4] = (float)p.d[0];
             sphere_medium = 1u << 7;
         }
-        L.meta = (uint32_t)p.type | ((uint32_t)p.axis << 2) | ((uint32_t)fs.materials[p.mat].type << 4) | sphere_medium | (xform << 8);
+        const MaterialT<double> &pm = fs.materials[p.mat];
+        const uint32_t tex_kind = pm.tex >= 0 ? (uint32_t)fs.textures[pm.tex].type : 0u;
+        L.meta = (uint32_t)p.type | ((uint32_t)p.axis << 2) | ((uint32_t)pm.type << 4) | sphere_medium | (tex_kind << 8) | (xform << 12);
         fs.bleaves.push_back(L);
     }
 }

@@ -38,6 +38,7 @@ struct WfBuffers {
     float4 *ro, *rd, *thr, *sum;      // origin+time, direction, throughput, radiance sum of the slot
     int4 *meta;                       // current sample, depth, leaf slot the ray starts on, pixel
     float2 *hit;                      // t, leaf slot (int bits; -1 = miss) written by extend
+    unsigned char *key;               // regrouping key of the hit written by extend: material type * 4 + texture type, 31 = miss
     int *active[2];                   // slot lists (ping-pong across compactions); -1 = hole
     unsigned *counters;               // 16 words: [0] live slots, [1] compaction cursor
     unsigned long long *stats;        // wf_stats_bytes(): [0] rays, [1] extend waves; 16 striped partial counters behind

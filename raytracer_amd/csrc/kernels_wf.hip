@@ -22,6 +22,10 @@
 #include "device/rt_shade.hpp"
 #include "kernels.h"
 
+#ifndef RT_WF_REGROUP
+#define RT_WF_REGROUP 1   // 0: shade in list order (kept for the A/B measurement in DESIGN.md)
+#endif
+
 namespace {
 
 
@@ -93,6 +97,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) k
         LdsStack stack(lds_stack + threadIdx.x, 256, sc.bvh_depth);
         const HitS h = bvh_closest_hit(sc, r, 0.001f, Mth<float>::inf(), stack, medium, m.z);   // ray.c:56
         B.hit[slot] = make_float2(h.t, __int_as_float(h.slot));
+        const uint32_t lm = h.slot >= 0 ? sc.bleaves[h.slot].meta : 0u;
+        B.key[slot] = h.slot >= 0 ? (unsigned char)(((lm >> 4) & 7u) * 4u + ((lm >> 8) & 3u)) : (unsigned char)31;
 #if RT_EXP == 3 || RT_EXP == 4
         probe_n = (unsigned)h.prim;
 #endif
@@ -116,9 +122,33 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) k
     }
 }
 
-__global__ void __launch_bounds__(256) k_wf_shade(SceneT<float> sc, CameraT<float> cam, RenderParams P, WfBuffers B, int cur, unsigned n_list) {
-    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
-    const int slot = i < n_list ? B.active[cur][i] : -1;
+// Rays regrouped by material inside the workgroup: the kWfShadeBlock list entries of a block are counting-sorted in LDS by
+// (material type, texture type) of what they hit, then thread t shades the t-th entry of the sorted order.  Only slot
+// ids move (the path state stays where it is in HBM and the block's slots are neighbours, so the gathers stay inside a
+// few cache lines); a wave then runs one arm of the material switch instead of all of them.  No global atomics.
+constexpr int kWfShadeBlock = 512;
+__global__ void __launch_bounds__(kWfShadeBlock) k_wf_shade(SceneT<float> sc, CameraT<float> cam, RenderParams P, WfBuffers B, int cur, unsigned n_list) {
+    __shared__ unsigned key_count[32], key_start[32];
+    __shared__ int sorted_slot[kWfShadeBlock];
+    __shared__ unsigned sorted_index[kWfShadeBlock];
+    unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    int slot = i < n_list ? B.active[cur][i] : -1;
+#if RT_WF_REGROUP
+    {
+        if (threadIdx.x < 32) key_count[threadIdx.x] = 0;
+        __syncthreads();
+        const unsigned key = slot >= 0 ? B.key[slot] & 31u : 0u;
+        const unsigned rank = slot >= 0 ? atomicAdd(&key_count[key], 1u) : 0u;
+        __syncthreads();
+        if (threadIdx.x == 0) { unsigned acc = 0; for (int k = 0; k < 32; ++k) { key_start[k] = acc; acc += key_count[k]; } key_count[0] = acc; }
+        __syncthreads();
+        const unsigned total = key_count[0];
+        if (slot >= 0) { const unsigned pos = key_start[key] + rank; sorted_slot[pos] = slot; sorted_index[pos] = i; }
+        __syncthreads();
+        slot = threadIdx.x < total ? sorted_slot[threadIdx.x] : -1;
+        i = threadIdx.x < total ? sorted_index[threadIdx.x] : 0u;
+    }
+#endif
     bool died = false;
     if (slot >= 0) {
         const float4 o = B.ro[slot], d = B.rd[slot], T4 = B.thr[slot];
@@ -203,7 +233,7 @@ __global__ void __launch_bounds__(256) k_wf_finish(RenderParams P, WfBuffers B, 
 
 }  // namespace
 
-size_t wf_bytes_per_slot() { return 4 * sizeof(float4) + sizeof(int4) + sizeof(float2) + 2 * sizeof(int); }
+size_t wf_bytes_per_slot() { return 4 * sizeof(float4) + sizeof(int4) + sizeof(float2) + 2 * sizeof(int) + 1; }
 size_t wf_stats_bytes() { return 17 * 8 * sizeof(unsigned long long); }   // 17 cache lines of 64 bytes
 
 hipError_t launch_wf_init(const CameraT<float> &cam, const RenderParams &p, const WfBuffers &b, hipStream_t stream) {
@@ -218,7 +248,7 @@ hipError_t launch_wf_bounce(const SceneT<float> &sc, const CameraT<float> &cam, 
     if (n_list == 0) return hipSuccess;
     const unsigned blocks = (n_list + 255) / 256;
     hipLaunchKernelGGL(k_wf_extend, dim3(blocks), dim3(256), (size_t)sc.bvh_depth * 256 * sizeof(int), stream, sc, p, b, cur, n_list);
-    hipLaunchKernelGGL(k_wf_shade, dim3(blocks), dim3(256), 0, stream, sc, cam, p, b, cur, n_list);
+    hipLaunchKernelGGL(k_wf_shade, dim3((n_list + kWfShadeBlock - 1) / kWfShadeBlock), dim3(kWfShadeBlock), 0, stream, sc, cam, p, b, cur, n_list);
     return hipGetLastError();
 }
 hipError_t launch_wf_compact(const WfBuffers &b, int cur, unsigned n_list, hipStream_t stream) {

@@ -300,6 +300,7 @@ static int render_wavefront(rtc_scene *s, const CameraT<float> &camf, const Rend
     b.hit = (float2 *)base; base += n * sizeof(float2);
     b.active[0] = (int *)base; base += n * sizeof(int);
     b.active[1] = (int *)base; base += n * sizeof(int);
+    b.key = (unsigned char *)base; base += n;
     b.stats = (unsigned long long *)s->ray_counter.p;
     b.counters = (unsigned *)((char *)s->ray_counter.p + wf_stats_bytes());
     b.n_slots = (int)n_slots; b.slots_per_layer = (int)per_layer; b.layers = (int)layers;

@@ -47,8 +47,9 @@ inline int rtc_leaf_ref(int first, int count) { return ~((first << 3) | (count -
 //   rect   : d = k lo_a lo_b hi_a hi_b   (a,b = in-plane axes: XY->x,y  XZ->x,z  YZ->y,z)
 //   medium : boundary = one sphere (meta bit 7): d = cx cy cz r neg_inv_density (world space);
 //            any other boundary: nothing here, the record is prims[leaf_prims[s]]
-// meta: bits 0-1 RTC_PRIM_*, bits 2-3 rect axis, bits 4-6 material type (ray regrouping key), bit 7 sphere-bounded
-//       medium, bits 8.. xform id
+// meta: bits 0-1 RTC_PRIM_*, bits 2-3 rect axis, bits 4-6 material type, bit 7 sphere-bounded medium, bits 8-9 texture
+//       type of the material (material + texture type = the ray regrouping key of the wavefront shade stage),
+//       bits 12.. xform id
 struct alignas(32) BLeaf { float d[7]; uint32_t meta; };
 struct BXform { float m[9]; float b[3]; };   // x_obj = M x_world + b
 

@@ -88,6 +88,7 @@ def cpu_baseline(budget_s=15.0):
 
 
 def main():
+    global WIDTH, HEIGHT
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -98,7 +99,6 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--png", default="", help="write the last frame here (rank 0)")
     a = ap.parse_args()
-    global WIDTH, HEIGHT
     WIDTH, HEIGHT = a.width, a.height
 
     rank = int(os.environ.get("RANK", "0"))

@@ -103,6 +103,7 @@ struct rtc_scene {
     DeviceTables<float> f32;
     DeviceTables<double> f64;
     DevBuf ray_counter;
+    DevBuf tile_scratch; size_t tile_scratch_cap = 0;   // small-scene kernel: cost + order of the 8x8 tiles
     DevBuf wf_pool; size_t wf_slots_cap = 0;   // wavefront path-slot state, grown on demand
     DevBuf small_pairs, small_groups, small_spheres, small_shade, small_xforms;
     SmallScene small{};   // n_leaves == 0: not eligible
@@ -350,7 +351,14 @@ int rtc_render_device(const rtc_scene *scene_c, const camera *cam, const rtc_set
     const bool wavefront = st->kernel == 3 || (st->kernel == 0 && !small && s->f32.view.n_nodes > 0);
     if (wavefront && s->f32.view.n_nodes <= 0)
         return fail(RTC_ERR_SCENE, "kernel 3 (wavefront) needs a scene that was flattened into a BVH (more than 64 leaves)");
-    if (small) HIP_TRY(launch_pathtrace_small(s->small, s->f32.view, camf, p, (float4 *)accum_dev, (unsigned long long *)s->ray_counter.p, stream));
+    if (small) {
+        if ((size_t)p.n_tiles > s->tile_scratch_cap) {
+            if (s->tile_scratch.p) { HIP_TRY(hipStreamSynchronize(stream)); (void)hipFree(s->tile_scratch.p); s->tile_scratch.p = nullptr; s->tile_scratch_cap = 0; }
+            if (hipMalloc(&s->tile_scratch.p, 2 * (size_t)p.n_tiles * sizeof(int)) == hipSuccess) s->tile_scratch_cap = (size_t)p.n_tiles;
+            else s->tile_scratch.p = nullptr;                       // no scratch: tiles run in image order
+        }
+        HIP_TRY(launch_pathtrace_small(s->small, s->f32.view, camf, p, (float4 *)accum_dev, (unsigned long long *)s->ray_counter.p, (int *)s->tile_scratch.p, stream));
+    }
     else if (wavefront) { rc = render_wavefront(s, camf, p, st, (float4 *)accum_dev, stream); if (rc) return rc; }
     else HIP_TRY(launch_pathtrace_mega(s->f32.view, camf, p, (float4 *)accum_dev, (unsigned long long *)s->ray_counter.p, stream));
     ss.kernel = small ? 2 : (wavefront ? 3 : 1);

@@ -465,7 +465,7 @@ void build_small_pack(FlatScene &fs) {
         items.push_back(it);
     }
     std::stable_sort(items.begin(), items.end(), [](const Item &a, const Item &b) { return a.key < b.key; });
-    std::vector<SmallPair> pairs; std::vector<SmallGroup> groups; std::vector<SmallSphere> spheres; std::vector<SmallShade> shade;
+    std::vector<SmallPair> pairs; std::vector<SmallGroup> groups; std::vector<SmallSphere> spheres; std::vector<SmallShade> shade; std::vector<SmallBox> boxes;
     const float never[5] = {0.0f, HUGE_VALF, HUGE_VALF, -HUGE_VALF, -HUGE_VALF};
     SmallShade none; std::memset(&none, 0, sizeof none);
     size_t i = 0;
@@ -486,10 +486,34 @@ void build_small_pack(FlatScene &fs) {
             }
             (axis == 0 ? g.n_xy : axis == 1 ? g.n_xz : g.n_yz) = count;
         }
+        g.box = -1;
+        if (g.n_xy == 1 && g.n_xz == 1 && g.n_yz == 1) {             // a closed box?  (SmallBox, rtc_tables.h)
+            const SmallPair &XY = pairs[g.first], &XZ = pairs[g.first + 1], &YZ = pairs[g.first + 2];
+            auto lo2 = [](const SmallPair &P) { return std::min(P.f[0], P.f[1]); };
+            auto hi2 = [](const SmallPair &P) { return std::max(P.f[0], P.f[1]); };
+            const float lo[3] = {lo2(YZ), lo2(XZ), lo2(XY)}, hi[3] = {hi2(YZ), hi2(XZ), hi2(XY)};
+            auto bounds = [](const SmallPair &P, float a0, float b0, float a1, float b1) {   // both rects span [a0,a1] x [b0,b1]
+                return P.f[2] == a0 && P.f[3] == b0 && P.f[4] == a1 && P.f[5] == b1 && P.f[6] == a0 && P.f[7] == b0 && P.f[8] == a1 && P.f[9] == b1;
+            };
+            const bool closed = lo[0] < hi[0] && lo[1] < hi[1] && lo[2] < hi[2] && std::isfinite(hi[0]) && std::isfinite(hi[1]) && std::isfinite(hi[2])
+                                && bounds(XY, lo[0], lo[1], hi[0], hi[1]) && bounds(XZ, lo[0], lo[2], hi[0], hi[2]) && bounds(YZ, lo[1], lo[2], hi[1], hi[2]);
+            if (closed) {
+                SmallBox B; std::memset(&B, 0, sizeof B);
+                const SmallPair *face[3] = {&YZ, &XZ, &XY}; const int pair_of[3] = {g.first + 2, g.first + 1, g.first};
+                for (int a = 0; a < 3; a++) {
+                    B.lo[a] = lo[a]; B.hi[a] = hi[a];
+                    const int j_lo = face[a]->f[0] == lo[a] ? 0 : 1;
+                    B.ids_lo |= (uint32_t)(2 * pair_of[a] + j_lo) << (8 * a);
+                    B.ids_hi |= (uint32_t)(2 * pair_of[a] + (1 - j_lo)) << (8 * a);
+                }
+                g.box = (int)boxes.size(); boxes.push_back(B);
+            }
+        }
         groups.push_back(g);
     }
     for (; i < items.size(); i++) { spheres.push_back(items[i].sph); shade.push_back(items[i].S); }
     if (shade.size() > RTC_SMALL_MAX_LEAVES) return;
+    fs.small_boxes = boxes;
     fs.small_pairs = pairs; fs.small_groups = groups; fs.small_spheres = spheres; fs.small_shade = shade; fs.small_xforms = xf;
     fs.small_any_fuzz = any_fuzz; fs.small_ok = true;
 }

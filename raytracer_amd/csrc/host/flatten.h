@@ -27,6 +27,7 @@ struct FlatScene {
     // small-scene pack (empty when the scene is not eligible: see build_small_pack in flatten.cpp)
     std::vector<SmallPair> small_pairs;
     std::vector<SmallGroup> small_groups;
+    std::vector<SmallBox> small_boxes;
     std::vector<SmallSphere> small_spheres;
     std::vector<SmallShade> small_shade;
     std::vector<SmallXform> small_xforms;

@@ -65,6 +65,27 @@ RT_DEV void small_run(const SmallScene &ss, int first, int count, float on, floa
     const v2f oab = {oa, ob}, dab = {da, db};
     for (int p = first; p < first + count; ++p) small_pair(ss.pairs[p], 2 * p, on, in, oab, dab, tmin, h);   // wave-uniform: one s_load_dwordx16
 }
+// box_hit (hittable.c:521-523 = the list scan over the six sides) as one slab test: the surface is entered at the largest
+// near-plane parameter and left at the smallest far-plane parameter; a ray that starts inside (or on) the box hits the
+// exit face.  The face gives the leaf id, so shading sees the same record as after six rect tests.
+RT_DEV void small_box(const SmallBox &B, f3 o, f3 inv, float tmin, SmallHit &h) {
+    const float x0 = (B.lo[0] - o.x) * inv.x, x1 = (B.hi[0] - o.x) * inv.x;
+    const float y0 = (B.lo[1] - o.y) * inv.y, y1 = (B.hi[1] - o.y) * inv.y;
+    const float z0 = (B.lo[2] - o.z) * inv.z, z1 = (B.hi[2] - o.z) * inv.z;
+    const float nx = fminf(x0, x1), ny = fminf(y0, y1), nz = fminf(z0, z1);
+    const float fx = fmaxf(x0, x1), fy = fmaxf(y0, y1), fz = fmaxf(z0, z1);
+    const float t_in = fmaxf(fmaxf(nx, ny), nz), t_out = fminf(fminf(fx, fy), fz);
+    const bool enter = t_in >= tmin;
+    const float t = enter ? t_in : t_out;
+    const bool hit = (t_in <= t_out) & (t >= tmin) & (t <= h.t);
+    // face: the axis that set t, and on that axis the plane the ray meets first (enter) or last (exit)
+    const int ax = enter ? (nx == t_in ? 0 : (ny == t_in ? 1 : 2)) : (fx == t_out ? 0 : (fy == t_out ? 1 : 2));
+    const float inv_ax = ax == 0 ? inv.x : (ax == 1 ? inv.y : inv.z);
+    const bool at_hi = (inv_ax > 0.0f) != enter;
+    const uint32_t ids = at_hi ? B.ids_hi : B.ids_lo;
+    const int id = (int)((ids >> (8 * ax)) & 0xffu);
+    h.t = hit ? t : h.t; h.leaf = hit ? id : h.leaf;
+}
 // hittable_list_hit (hittable_list.c:125-143) over the packed leaves.  `src` = leaf the ray starts on: only spheres need
 // it (rt_core.hpp sphere_leave_t); a rect left behind is rejected by tmin like in the reference.
 RT_DEV SmallHit small_closest_hit(const SmallScene &ss, f3 ow, f3 dw, float tmin, int src) {
@@ -74,6 +95,7 @@ RT_DEV SmallHit small_closest_hit(const SmallScene &ss, f3 ow, f3 dw, float tmin
         const SmallGroup g = ss.groups[gi];                      // wave-uniform
         f3 o = ow, d = dw, inv = invw;
         if (g.xform != 0) { const SmallXform x = ss.xforms[g.xform]; o = xform_point(x, ow); d = xform_dir(x, dw); inv = rcp3(d); }
+        if (g.box >= 0) { small_box(ss.boxes[g.box], o, inv, tmin, h); continue; }
         int first = g.first;
         small_run(ss, first, g.n_xy, o.z, inv.z, o.x, d.x, o.y, d.y, tmin, h); first += g.n_xy;
         small_run(ss, first, g.n_xz, o.y, inv.y, o.x, d.x, o.z, d.z, tmin, h); first += g.n_xz;

@@ -105,7 +105,7 @@ struct rtc_scene {
     DevBuf ray_counter;
     DevBuf tile_scratch; size_t tile_scratch_cap = 0;   // small-scene kernel: cost + order of the 8x8 tiles
     DevBuf wf_pool; size_t wf_slots_cap = 0;   // wavefront path-slot state, grown on demand
-    DevBuf small_pairs, small_groups, small_spheres, small_shade, small_xforms;
+    DevBuf small_pairs, small_groups, small_spheres, small_shade, small_xforms, small_boxes;
     SmallScene small{};   // n_leaves == 0: not eligible
     std::map<void *, StreamState> streams;
     std::mutex mu;
@@ -148,7 +148,9 @@ rtc_scene *rtc_scene_build(const hittable_list *world, const hittable_list *ligh
         if (e == hipSuccess) e = s->small_spheres.upload(fs.small_spheres.data(), fs.small_spheres.size() * sizeof(SmallSphere));
         if (e == hipSuccess) e = s->small_shade.upload(fs.small_shade.data(), fs.small_shade.size() * sizeof(SmallShade));
         if (e == hipSuccess) e = s->small_xforms.upload(fs.small_xforms.data(), fs.small_xforms.size() * sizeof(SmallXform));
+        if (e == hipSuccess) e = s->small_boxes.upload(fs.small_boxes.data(), fs.small_boxes.size() * sizeof(SmallBox));
         SmallScene &m = s->small;
+        m.boxes = (const SmallBox *)s->small_boxes.p;
         m.pairs = (const SmallPair *)s->small_pairs.p; m.groups = (const SmallGroup *)s->small_groups.p;
         m.spheres = (const SmallSphere *)s->small_spheres.p; m.shade = (const SmallShade *)s->small_shade.p;
         m.xforms = (const SmallXform *)s->small_xforms.p;

@@ -95,12 +95,17 @@ template <typename R> struct SceneT {
 enum { RTC_SMALL_MAX_LEAVES = 64, RTC_SMALL_MAX_XFORMS = 16 };
 enum { RTC_SF_FORCED_FRONT = 1u << 8, RTC_SF_FLIP = 1u << 9, RTC_SF_SPHERE = 1u << 10 };   // SmallShade.meta bits; bits 0-7 = material type
 struct alignas(64) SmallPair { float f[16]; };
-struct alignas(32) SmallGroup { int xform, first, n_xy, n_xz, n_yz, pad0, pad1, pad2; };
+struct alignas(32) SmallGroup { int xform, first, n_xy, n_xz, n_yz, box, pad1, pad2; };   // box >= 0: the group is exactly one box, see SmallBox
+// Six rects of one object space that form a closed axis-aligned box (hittable_box_new, hittable.c:139-155): ONE slab test
+// (~35 VALU instructions) replaces three pair tests (~78).  ids_lo / ids_hi = leaf ids of the x, y, z faces at lo / hi,
+// one byte each.  The pairs stay in the table (leaf ids are positions in it) but are not read by the traversal.
+struct alignas(32) SmallBox { float lo[3], hi[3]; uint32_t ids_lo, ids_hi; };
 struct alignas(16) SmallSphere { float c[3]; float r2; };
 struct alignas(16) SmallShade { uint32_t meta; float rgb[3]; float g[4]; float param; float pad[3]; };
 struct SmallXform { float m[9]; float b[3]; };
 struct SmallScene {
     const SmallPair *pairs; const SmallGroup *groups; const SmallSphere *spheres; const SmallShade *shade; const SmallXform *xforms;
+    const SmallBox *boxes;
     int n_pairs, n_groups, n_spheres, n_xforms;
     int n_leaves;                                  // 2 * n_pairs + n_spheres (padding slots included)
     int any_fuzz;                                  // some metal has fuzz > 0

@@ -467,51 +467,80 @@ void build_small_pack(FlatScene &fs) {
     std::stable_sort(items.begin(), items.end(), [](const Item &a, const Item &b) { return a.key < b.key; });
     std::vector<SmallPair> pairs; std::vector<SmallGroup> groups; std::vector<SmallSphere> spheres; std::vector<SmallShade> shade; std::vector<SmallBox> boxes;
     const float never[5] = {0.0f, HUGE_VALF, HUGE_VALF, -HUGE_VALF, -HUGE_VALF};
-    SmallShade none; std::memset(&none, 0, sizeof none);
+    // leaf id = index into `shade`: the rects in sorted order, then the spheres
+    size_t n_rects = 0;
+    while (n_rects < items.size() && items[n_rects].key < (1 << 20)) n_rects++;
+    for (const Item &it : items) shade.push_back(it.S);
+    auto id_bits = [](int id) { float f; std::memcpy(&f, &id, sizeof f); return f; };
     size_t i = 0;
-    while (i < items.size() && items[i].key < (1 << 20)) {
+    while (i < n_rects) {
         SmallGroup g; std::memset(&g, 0, sizeof g);
-        g.xform = items[i].key / 4; g.first = (int)pairs.size();
+        g.xform = items[i].key / 4; g.first = (int)pairs.size(); g.box = -1;
+        size_t end = i;
+        while (end < n_rects && items[end].key / 4 == g.xform) end++;
+        // ---- the largest set of rects of this space that are faces of ONE axis-aligned box (SmallBox, rtc_tables.h) ----
+        // extent of item r on axis e: its plane (lo == hi == k) on its own axis, its bounds on the other two
+        auto axis_of = [&](size_t r) { const int ax = items[r].key & 3; return ax == RTC_AXIS_YZ ? 0 : (ax == RTC_AXIS_XZ ? 1 : 2); };   // normal axis: x, y, z
+        auto extent = [&](size_t r, int e, float &lo, float &hi) {
+            const float *q = items[r].rect; const int n = axis_of(r);
+            if (e == n) { lo = hi = q[0]; return; }
+            // in-plane axes (a, b): XY -> x,y  XZ -> x,z  YZ -> y,z
+            const int a = n == 0 ? 1 : 0;
+            if (e == a) { lo = q[1]; hi = q[3]; } else { lo = q[2]; hi = q[4]; }
+        };
+        std::vector<int> best_face;   // per chosen candidate: item index of face (axis * 2 + side) or -1
+        int best_count = 0; float best_lo[3] = {0, 0, 0}, best_hi[3] = {0, 0, 0};
+        for (size_t r0 = i; r0 < end; r0++)
+            for (size_t r1 = i; r1 < end; r1++) {
+                if (axis_of(r0) == axis_of(r1)) continue;
+                float lo[3], hi[3]; const int n0 = axis_of(r0);
+                for (int e = 0; e < 3; e++) { if (e == n0) extent(r1, e, lo[e], hi[e]); else extent(r0, e, lo[e], hi[e]); }
+                if (!(lo[0] < hi[0] && lo[1] < hi[1] && lo[2] < hi[2]) || !std::isfinite(hi[0] - lo[0]) || !std::isfinite(hi[1] - lo[1]) || !std::isfinite(hi[2] - lo[2])) continue;
+                std::vector<int> face(6, -1); int count = 0;
+                for (size_t r = i; r < end; r++) {
+                    const int n = axis_of(r); bool ok = true; int side = -1;
+                    for (int e = 0; e < 3 && ok; e++) {
+                        float l, h; extent(r, e, l, h);
+                        if (e == n) { side = l == lo[e] ? 0 : (l == hi[e] ? 1 : -1); ok = side >= 0; }
+                        else ok = l == lo[e] && h == hi[e];
+                    }
+                    if (ok && face[2 * n + side] < 0) { face[2 * n + side] = (int)r; count++; }
+                }
+                if (count > best_count) { best_count = count; best_face = face; for (int e = 0; e < 3; e++) { best_lo[e] = lo[e]; best_hi[e] = hi[e]; } }
+            }
+        std::vector<char> in_box(end - i, 0);
+        if (best_count >= 3) {                                        // one slab test beats two or more pair tests
+            SmallBox B; std::memset(&B, 0, sizeof B);
+            for (int e = 0; e < 3; e++) {
+                B.lo[e] = best_lo[e]; B.hi[e] = best_hi[e];
+                const int f_lo = best_face[2 * e], f_hi = best_face[2 * e + 1];
+                B.ids_lo |= (uint32_t)(f_lo >= 0 ? f_lo : 0xff) << (8 * e);
+                B.ids_hi |= (uint32_t)(f_hi >= 0 ? f_hi : 0xff) << (8 * e);
+                if (f_lo >= 0) in_box[(size_t)f_lo - i] = 1;
+                if (f_hi >= 0) in_box[(size_t)f_hi - i] = 1;
+            }
+            g.box = (int)boxes.size(); boxes.push_back(B);
+        }
+        // ---- the other rects: pairs per axis ----
         for (int axis = 0; axis < 3; axis++) {                      // RTC_AXIS_XY, _XZ, _YZ in this order
+            std::vector<size_t> run;
+            for (size_t r = i; r < end; r++) if ((items[r].key & 3) == axis && !in_box[r - i]) run.push_back(r);
             int count = 0;
-            while (i < items.size() && items[i].key == g.xform * 4 + axis) {
-                const float *r0 = items[i].rect, *r1 = never;
-                shade.push_back(items[i].S);
-                if (i + 1 < items.size() && items[i + 1].key == items[i].key) { r1 = items[i + 1].rect; shade.push_back(items[i + 1].S); i += 2; }
-                else { shade.push_back(none); i += 1; }
+            for (size_t k = 0; k < run.size(); k += 2) {
+                const float *r0 = items[run[k]].rect, *r1 = k + 1 < run.size() ? items[run[k + 1]].rect : never;
                 SmallPair P; std::memset(&P, 0, sizeof P);
                 P.f[0] = r0[0]; P.f[1] = r1[0];
-                for (int k = 0; k < 4; k++) { P.f[2 + k] = r0[1 + k]; P.f[6 + k] = r1[1 + k]; }
+                for (int c = 0; c < 4; c++) { P.f[2 + c] = r0[1 + c]; P.f[6 + c] = r1[1 + c]; }
+                P.f[10] = id_bits((int)run[k]); P.f[11] = id_bits(k + 1 < run.size() ? (int)run[k + 1] : -1);
                 pairs.push_back(P); count++;
             }
             (axis == 0 ? g.n_xy : axis == 1 ? g.n_xz : g.n_yz) = count;
         }
-        g.box = -1;
-        if (g.n_xy == 1 && g.n_xz == 1 && g.n_yz == 1) {             // a closed box?  (SmallBox, rtc_tables.h)
-            const SmallPair &XY = pairs[g.first], &XZ = pairs[g.first + 1], &YZ = pairs[g.first + 2];
-            auto lo2 = [](const SmallPair &P) { return std::min(P.f[0], P.f[1]); };
-            auto hi2 = [](const SmallPair &P) { return std::max(P.f[0], P.f[1]); };
-            const float lo[3] = {lo2(YZ), lo2(XZ), lo2(XY)}, hi[3] = {hi2(YZ), hi2(XZ), hi2(XY)};
-            auto bounds = [](const SmallPair &P, float a0, float b0, float a1, float b1) {   // both rects span [a0,a1] x [b0,b1]
-                return P.f[2] == a0 && P.f[3] == b0 && P.f[4] == a1 && P.f[5] == b1 && P.f[6] == a0 && P.f[7] == b0 && P.f[8] == a1 && P.f[9] == b1;
-            };
-            const bool closed = lo[0] < hi[0] && lo[1] < hi[1] && lo[2] < hi[2] && std::isfinite(hi[0]) && std::isfinite(hi[1]) && std::isfinite(hi[2])
-                                && bounds(XY, lo[0], lo[1], hi[0], hi[1]) && bounds(XZ, lo[0], lo[2], hi[0], hi[2]) && bounds(YZ, lo[1], lo[2], hi[1], hi[2]);
-            if (closed) {
-                SmallBox B; std::memset(&B, 0, sizeof B);
-                const SmallPair *face[3] = {&YZ, &XZ, &XY}; const int pair_of[3] = {g.first + 2, g.first + 1, g.first};
-                for (int a = 0; a < 3; a++) {
-                    B.lo[a] = lo[a]; B.hi[a] = hi[a];
-                    const int j_lo = face[a]->f[0] == lo[a] ? 0 : 1;
-                    B.ids_lo |= (uint32_t)(2 * pair_of[a] + j_lo) << (8 * a);
-                    B.ids_hi |= (uint32_t)(2 * pair_of[a] + (1 - j_lo)) << (8 * a);
-                }
-                g.box = (int)boxes.size(); boxes.push_back(B);
-            }
-        }
         groups.push_back(g);
+        i = end;
     }
-    for (; i < items.size(); i++) { spheres.push_back(items[i].sph); shade.push_back(items[i].S); }
+    for (i = n_rects; i < items.size(); i++) spheres.push_back(items[i].sph);
+    fs.small_n_rects = (int)n_rects;
     if (shade.size() > RTC_SMALL_MAX_LEAVES) return;
     fs.small_boxes = boxes;
     fs.small_pairs = pairs; fs.small_groups = groups; fs.small_spheres = spheres; fs.small_shade = shade; fs.small_xforms = xf;

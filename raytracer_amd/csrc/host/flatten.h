@@ -32,6 +32,7 @@ struct FlatScene {
     std::vector<SmallShade> small_shade;
     std::vector<SmallXform> small_xforms;
     bool small_ok = false, small_any_fuzz = false;
+    int small_n_rects = 0;         // leaf ids: rects 0 .. small_n_rects-1, then the spheres
     std::vector<int> wrap_depth;   // per prim: number of translate/rotate wrappers (for rtc_scene_dump_leaves)
     std::vector<int> flipped;      // per prim: parity of flip_face wrappers
     int n_media = 0;

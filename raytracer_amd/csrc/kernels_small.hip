@@ -41,8 +41,9 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 //   max(lo - p, p - hi, tmin - t, t - tbest) <= 0
 // so no lane masks are combined on the (single, shared) scalar unit; packed FP32 math does both in-plane axes at once.
 // tbest starts at a large FINITE value: a t of +inf (dn == 0) then violates t - tbest, NaNs fail the compare.
-RT_DEV void small_pair(const SmallPair &P, int id0, float on, float in, v2f oab, v2f dab, float tmin, SmallHit &h) {
+RT_DEV void small_pair(const SmallPair &P, float on, float in, v2f oab, v2f dab, float tmin, SmallHit &h) {
     const v2f k = {P.f[0], P.f[1]};
+    const int id0 = __float_as_int(P.f[10]), id1 = __float_as_int(P.f[11]);
     const v2f t = (k - on) * in;
     {
         const v2f p = oab + dab * t.x;
@@ -58,14 +59,14 @@ RT_DEV void small_pair(const SmallPair &P, int id0, float on, float in, v2f oab,
         const v2f vl = lo - p, vh = p - hi;
         const float viol = fmaxf(fmaxf(fmaxf(vl.x, vl.y), fmaxf(vh.x, vh.y)), fmaxf(tmin - t.y, t.y - h.t));
         const bool hit = viol <= 0.0f;
-        h.t = hit ? t.y : h.t; h.leaf = hit ? id0 + 1 : h.leaf;
+        h.t = hit ? t.y : h.t; h.leaf = hit ? id1 : h.leaf;
     }
 }
 RT_DEV void small_run(const SmallScene &ss, int first, int count, float on, float in, float oa, float da, float ob, float db, float tmin, SmallHit &h) {
     const v2f oab = {oa, ob}, dab = {da, db};
-    for (int p = first; p < first + count; ++p) small_pair(ss.pairs[p], 2 * p, on, in, oab, dab, tmin, h);   // wave-uniform: one s_load_dwordx16
+    for (int p = first; p < first + count; ++p) small_pair(ss.pairs[p], on, in, oab, dab, tmin, h);   // wave-uniform: one s_load_dwordx16
 }
-// box_hit (hittable.c:521-523 = the list scan over the six sides) as one slab test: the surface is entered at the largest
+// box_hit (hittable.c:521-523 = the list scan over the sides) as one slab test, also for a box with openings: the surface is entered at the largest
 // near-plane parameter and left at the smallest far-plane parameter; a ray that starts inside (or on) the box hits the
 // exit face.  The face gives the leaf id, so shading sees the same record as after six rect tests.
 RT_DEV void small_box(const SmallBox &B, f3 o, f3 inv, float tmin, SmallHit &h) {
@@ -75,16 +76,18 @@ RT_DEV void small_box(const SmallBox &B, f3 o, f3 inv, float tmin, SmallHit &h) 
     const float nx = fminf(x0, x1), ny = fminf(y0, y1), nz = fminf(z0, z1);
     const float fx = fmaxf(x0, x1), fy = fmaxf(y0, y1), fz = fmaxf(z0, z1);
     const float t_in = fmaxf(fmaxf(nx, ny), nz), t_out = fminf(fminf(fx, fy), fz);
-    const bool enter = t_in >= tmin;
+    // faces: the axis that set the parameter, and on that axis the plane met first (entry) or last (exit)
+    const int ax_in = nx == t_in ? 0 : (ny == t_in ? 1 : 2), ax_out = fx == t_out ? 0 : (fy == t_out ? 1 : 2);
+    const float inv_in = ax_in == 0 ? inv.x : (ax_in == 1 ? inv.y : inv.z), inv_out = ax_out == 0 ? inv.x : (ax_out == 1 ? inv.y : inv.z);
+    const uint32_t id_in = ((inv_in > 0.0f ? B.ids_lo : B.ids_hi) >> (8 * ax_in)) & 0xffu;
+    const uint32_t id_out = ((inv_out > 0.0f ? B.ids_hi : B.ids_lo) >> (8 * ax_out)) & 0xffu;
+    // the entry point counts when it is in range and that face exists; otherwise (ray starts inside, or enters through an
+    // opening) the exit point
+    const bool enter = (t_in >= tmin) & (id_in != 0xffu);
     const float t = enter ? t_in : t_out;
-    const bool hit = (t_in <= t_out) & (t >= tmin) & (t <= h.t);
-    // face: the axis that set t, and on that axis the plane the ray meets first (enter) or last (exit)
-    const int ax = enter ? (nx == t_in ? 0 : (ny == t_in ? 1 : 2)) : (fx == t_out ? 0 : (fy == t_out ? 1 : 2));
-    const float inv_ax = ax == 0 ? inv.x : (ax == 1 ? inv.y : inv.z);
-    const bool at_hi = (inv_ax > 0.0f) != enter;
-    const uint32_t ids = at_hi ? B.ids_hi : B.ids_lo;
-    const int id = (int)((ids >> (8 * ax)) & 0xffu);
-    h.t = hit ? t : h.t; h.leaf = hit ? id : h.leaf;
+    const uint32_t id = enter ? id_in : id_out;
+    const bool hit = (t_in <= t_out) & (t >= tmin) & (t <= h.t) & (id != 0xffu);
+    h.t = hit ? t : h.t; h.leaf = hit ? (int)id : h.leaf;
 }
 // hittable_list_hit (hittable_list.c:125-143) over the packed leaves.  `src` = leaf the ray starts on: only spheres need
 // it (rt_core.hpp sphere_leave_t); a rect left behind is rejected by tmin like in the reference.
@@ -95,7 +98,7 @@ RT_DEV SmallHit small_closest_hit(const SmallScene &ss, f3 ow, f3 dw, float tmin
         const SmallGroup g = ss.groups[gi];                      // wave-uniform
         f3 o = ow, d = dw, inv = invw;
         if (g.xform != 0) { const SmallXform x = ss.xforms[g.xform]; o = xform_point(x, ow); d = xform_dir(x, dw); inv = rcp3(d); }
-        if (g.box >= 0) { small_box(ss.boxes[g.box], o, inv, tmin, h); continue; }
+        if (g.box >= 0) small_box(ss.boxes[g.box], o, inv, tmin, h);
         int first = g.first;
         small_run(ss, first, g.n_xy, o.z, inv.z, o.x, d.x, o.y, d.y, tmin, h); first += g.n_xy;
         small_run(ss, first, g.n_xz, o.y, inv.y, o.x, d.x, o.z, d.z, tmin, h); first += g.n_xz;
@@ -105,7 +108,7 @@ RT_DEV SmallHit small_closest_hit(const SmallScene &ss, f3 ow, f3 dw, float tmin
         const float inv_a = __builtin_amdgcn_rcpf(len2(dw));
         for (int s = 0; s < ss.n_spheres; ++s) {
             const SmallSphere sp = ss.spheres[s];
-            const int id = 2 * ss.n_pairs + s;
+            const int id = ss.n_rects + s;
             const f3 oc = ow - f3mk(sp.c[0], sp.c[1], sp.c[2]);
             const float tc = -dot(oc, dw) * inv_a;
             const f3 l = oc + dw * tc;

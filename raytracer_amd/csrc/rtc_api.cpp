@@ -154,7 +154,7 @@ rtc_scene *rtc_scene_build(const hittable_list *world, const hittable_list *ligh
         m.pairs = (const SmallPair *)s->small_pairs.p; m.groups = (const SmallGroup *)s->small_groups.p;
         m.spheres = (const SmallSphere *)s->small_spheres.p; m.shade = (const SmallShade *)s->small_shade.p;
         m.xforms = (const SmallXform *)s->small_xforms.p;
-        m.n_pairs = (int)fs.small_pairs.size(); m.n_groups = (int)fs.small_groups.size(); m.n_spheres = (int)fs.small_spheres.size();
+        m.n_rects = fs.small_n_rects; m.n_pairs = (int)fs.small_pairs.size(); m.n_groups = (int)fs.small_groups.size(); m.n_spheres = (int)fs.small_spheres.size();
         m.n_xforms = (int)fs.small_xforms.size(); m.n_leaves = (int)fs.small_shade.size(); m.any_fuzz = fs.small_any_fuzz;
     }
     if (e != hipSuccess) { g_error = std::string("rtc_scene_build: upload failed: ") + hipGetErrorString(e); delete s; return nullptr; }

@@ -85,20 +85,22 @@ template <typename R> struct SceneT {
 //   SmallPair  : 64 B = TWO rects of one (space, axis) run, read with ONE s_load_dwordx16 (the index is wave-uniform);
 //                f = k0 k1 | lo_a0 lo_b0 | hi_a0 hi_b0 | lo_a1 lo_b1 | hi_a1 hi_b1   (a,b = in-plane axes: XY->x,y
 //                XZ->x,z  YZ->y,z; (lo_a, lo_b) and (hi_a, hi_b) sit in aligned register pairs for packed FP32 math);
-//                a run of odd length ends with a never-hit rect (lo = +inf)
+//                | id0 id1 (int bits);  a run of odd length ends with a never-hit rect (lo = +inf)
 //   SmallGroup : 32 B per object space: xform id, first pair, pairs per axis
 //   SmallSphere: 16 B, world space (rotations/translations only move the centre): cx cy cz r*r
 //   SmallShade : 48 B, gathered per lane from LDS by the winning leaf: world-space outward normal (rect) or centre and
 //                1/r (sphere), resolved material (solid colour already looked up), flags
 //   SmallXform : the translate/rotate wrapper stack of a leaf collapsed to x_obj = M x_world + b (M a rotation)
-// Leaf ids (SmallShade index, `src`): rect j of pair p -> 2p + j; sphere s -> 2 * n_pairs + s.
+// Leaf ids (SmallShade index, `src`): rects first (a pair names its two ids in f[10], f[11] as int bits, a box in its id
+// bytes), then sphere s -> n_rects + s.
 enum { RTC_SMALL_MAX_LEAVES = 64, RTC_SMALL_MAX_XFORMS = 16 };
 enum { RTC_SF_FORCED_FRONT = 1u << 8, RTC_SF_FLIP = 1u << 9, RTC_SF_SPHERE = 1u << 10 };   // SmallShade.meta bits; bits 0-7 = material type
 struct alignas(64) SmallPair { float f[16]; };
-struct alignas(32) SmallGroup { int xform, first, n_xy, n_xz, n_yz, box, pad1, pad2; };   // box >= 0: the group is exactly one box, see SmallBox
-// Six rects of one object space that form a closed axis-aligned box (hittable_box_new, hittable.c:139-155): ONE slab test
-// (~35 VALU instructions) replaces three pair tests (~78).  ids_lo / ids_hi = leaf ids of the x, y, z faces at lo / hi,
-// one byte each.  The pairs stay in the table (leaf ids are positions in it) but are not read by the traversal.
+struct alignas(32) SmallGroup { int xform, first, n_xy, n_xz, n_yz, box, pad1, pad2; };   // box >= 0: SmallBox of this space, tested before the pairs
+// Rects of one object space that are faces of ONE axis-aligned box -- all six (hittable_box_new, hittable.c:139-155) or
+// some of them (the five walls of the Cornell room): one slab test (~35 VALU instructions) replaces up to three pair
+// tests (~78).  ids_lo / ids_hi = leaf ids of the x, y, z faces at lo / hi, one byte each, 0xff = the box has no such
+// face (a ray passes through the opening).
 struct alignas(32) SmallBox { float lo[3], hi[3]; uint32_t ids_lo, ids_hi; };
 struct alignas(16) SmallSphere { float c[3]; float r2; };
 struct alignas(16) SmallShade { uint32_t meta; float rgb[3]; float g[4]; float param; float pad[3]; };
@@ -107,7 +109,8 @@ struct SmallScene {
     const SmallPair *pairs; const SmallGroup *groups; const SmallSphere *spheres; const SmallShade *shade; const SmallXform *xforms;
     const SmallBox *boxes;
     int n_pairs, n_groups, n_spheres, n_xforms;
-    int n_leaves;                                  // 2 * n_pairs + n_spheres (padding slots included)
+    int n_rects;                                   // leaf id of sphere s = n_rects + s
+    int n_leaves;                                  // n_rects + n_spheres
     int any_fuzz;                                  // some metal has fuzz > 0
 };
 

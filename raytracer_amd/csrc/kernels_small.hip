@@ -158,7 +158,9 @@ RT_DEV f3 small_light_sample(const SceneT<float> &sc, int pick, f3 o, float r1, 
     return dir;
 }
 
-template <int INTEGRATOR>
+// PROBE = true: the one-sample cost probe of launch_pathtrace_small (its own kernel name in profiles): writes the rays of
+// each tile to tile_cost and nothing else.
+template <int INTEGRATOR, bool PROBE>
 __global__ void __launch_bounds__(256) k_pathtrace_small(SmallScene ss, SceneT<float> sc, CameraT<float> cam, RenderParams P,
                                                           float4 *__restrict__ accum, unsigned long long *__restrict__ counters,
                                                           const int *__restrict__ tile_perm, int *__restrict__ tile_cost) {
@@ -172,7 +174,7 @@ __global__ void __launch_bounds__(256) k_pathtrace_small(SmallScene ss, SceneT<f
     const int lane = threadIdx.x & 63;
     int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (tile >= P.n_tiles) return;   // wave-uniform, after the only barrier
-    if (tile_perm) tile = tile_perm[tile];   // heaviest tiles first (launch_pathtrace_small)
+    if (!PROBE && tile_perm) tile = tile_perm[tile];   // heaviest tiles first (launch_pathtrace_small)
     const int px = (tile % P.tiles_x) * 8 + (lane & 7), py = (tile / P.tiles_x) * 8 + (lane >> 3);
     const bool valid = px < P.width && py < P.height;
     const uint32_t pixel = (uint32_t)(py * P.width + px);
@@ -275,7 +277,7 @@ __global__ void __launch_bounds__(256) k_pathtrace_small(SmallScene ss, SceneT<f
     unsigned total = nrays;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) total += __shfl_xor(total, off, 64);
-    if (tile_cost) { if (lane == 0) tile_cost[tile] = (int)total; return; }   // cost probe: rays of this tile, nothing else is written
+    if (PROBE) { if (lane == 0) tile_cost[tile] = (int)total; return; }   // cost probe: rays of this tile, nothing else is written
     if (valid) {
         float4 a = accum[pixel];
         a.x += sum.x; a.y += sum.y; a.z += sum.z; a.w += (float)(P.s_end - P.s_begin);
@@ -299,12 +301,13 @@ __global__ void __launch_bounds__(1024) k_tile_order(const int *__restrict__ cos
 
 }  // namespace
 
+template <bool PROBE>
 static void launch_small(const SmallScene &ss, const SceneT<float> &sc, const CameraT<float> &cam, const RenderParams &p, float4 *accum,
                          unsigned long long *counters, const int *perm, int *cost, hipStream_t stream) {
     const unsigned blocks = (unsigned)((p.n_tiles + 3) / 4);
-    if (p.integrator == 0) hipLaunchKernelGGL(k_pathtrace_small<0>, dim3(blocks), dim3(256), 0, stream, ss, sc, cam, p, accum, counters, perm, cost);
-    else if (p.integrator == 1) hipLaunchKernelGGL(k_pathtrace_small<1>, dim3(blocks), dim3(256), 0, stream, ss, sc, cam, p, accum, counters, perm, cost);
-    else hipLaunchKernelGGL(k_pathtrace_small<2>, dim3(blocks), dim3(256), 0, stream, ss, sc, cam, p, accum, counters, perm, cost);
+    if (p.integrator == 0) hipLaunchKernelGGL((k_pathtrace_small<0, PROBE>), dim3(blocks), dim3(256), 0, stream, ss, sc, cam, p, accum, counters, perm, cost);
+    else if (p.integrator == 1) hipLaunchKernelGGL((k_pathtrace_small<1, PROBE>), dim3(blocks), dim3(256), 0, stream, ss, sc, cam, p, accum, counters, perm, cost);
+    else hipLaunchKernelGGL((k_pathtrace_small<2, PROBE>), dim3(blocks), dim3(256), 0, stream, ss, sc, cam, p, accum, counters, perm, cost);
 }
 
 // tile_scratch: 2 * n_tiles ints (cost, order) or NULL.  A wave owns a tile for all samples of the launch, and an interior
@@ -319,10 +322,10 @@ hipError_t launch_pathtrace_small(const SmallScene &ss, const SceneT<float> &sc,
     if (tile_scratch && p.s_end - p.s_begin >= 32 && p.n_tiles >= 2048 && p.max_depth > 0) {
         RenderParams probe = p; probe.s_end = probe.s_begin + 1;
         int *cost = tile_scratch, *order = tile_scratch + p.n_tiles;
-        launch_small(ss, sc, cam, probe, accum, counters, nullptr, cost, stream);
+        launch_small<true>(ss, sc, cam, probe, accum, counters, nullptr, cost, stream);
         hipLaunchKernelGGL(k_tile_order, dim3(1), dim3(1024), 0, stream, cost, p.n_tiles, order);
         perm = order;
     }
-    launch_small(ss, sc, cam, p, accum, counters, perm, nullptr, stream);
+    launch_small<false>(ss, sc, cam, p, accum, counters, perm, nullptr, stream);
     return hipGetLastError();
 }

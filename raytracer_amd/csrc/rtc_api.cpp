@@ -277,7 +277,7 @@ static int check_settings(const rtc_settings *st) {
 // Wavefront driver (kernels_wf.hip): init, then extend + shade per bounce until no slot is live, then the accumulate.
 // The live count is read back every few bounces, so this path returns only when the work has been ENQUEUED AND RUN up to
 // the final accumulate (which is left in flight on `stream`).
-static int render_wavefront(rtc_scene *s, const CameraT<float> &camf, const RenderParams &p, const rtc_settings *st, float4 *accum, hipStream_t stream) {
+static int render_wavefront(rtc_scene *s, const CameraT<float> &camf, const RenderParams &p, float4 *accum, hipStream_t stream) {
     const int spp = p.s_end - p.s_begin;
     if (spp <= 0) return RTC_OK;
     const long long per_layer = (long long)p.n_tiles * 64;
@@ -324,7 +324,6 @@ static int render_wavefront(rtc_scene *s, const CameraT<float> &camf, const Rend
         for (int k = 0; k < 8 && it < max_iterations; ++k, ++it) HIP_TRY(launch_wf_bounce(s->f32.view, camf, p, b, cur, n_list, stream));
     }
     HIP_TRY(launch_wf_finish(p, b, accum, stream));
-    (void)st;
     return RTC_OK;
 }
 
@@ -361,7 +360,7 @@ int rtc_render_device(const rtc_scene *scene_c, const camera *cam, const rtc_set
         }
         HIP_TRY(launch_pathtrace_small(s->small, s->f32.view, camf, p, (float4 *)accum_dev, (unsigned long long *)s->ray_counter.p, (int *)s->tile_scratch.p, stream));
     }
-    else if (wavefront) { rc = render_wavefront(s, camf, p, st, (float4 *)accum_dev, stream); if (rc) return rc; }
+    else if (wavefront) { rc = render_wavefront(s, camf, p, (float4 *)accum_dev, stream); if (rc) return rc; }
     else HIP_TRY(launch_pathtrace_mega(s->f32.view, camf, p, (float4 *)accum_dev, (unsigned long long *)s->ray_counter.p, stream));
     ss.kernel = small ? 2 : (wavefront ? 3 : 1);
     HIP_TRY(hipEventRecord(ss.ev1, stream));

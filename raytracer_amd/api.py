@@ -64,7 +64,7 @@ hittable_rect_new hittable_box_new hittable_moving_sphere_new bvh_node_init hitt
 hittable_rotate_init hittable_constant_medium_init hittable_constant_medium_init_c hittable_flip_face_init
 hittable_free camera_new camera_free camera_fields rt_scene_build rt_scene_set_image_path rt_write_png rt_write_ppm_p3""".split()
 RTC_SYMBOLS = """rtc_init rtc_last_error rtc_device_name rtc_scene_build rtc_scene_flatten_only rtc_scene_free rtc_scene_num_prims
-rtc_scene_dump_leaves rtc_scene_bvh_info rtc_first_hit_f64 rtc_first_hit_f32 rtc_primary_first_hit_f64 rtc_render_device rtc_render rtc_render_stats
+rtc_scene_dump_leaves rtc_scene_bvh_info rtc_scene_dump_bvh rtc_first_hit_f64 rtc_first_hit_f32 rtc_primary_first_hit_f64 rtc_render_device rtc_render rtc_render_stats
 rtc_tonemap_u8_device rtc_tonemap_u8""".split()
 
 
@@ -132,6 +132,7 @@ def lib():
     L.rtc_scene_num_prims.argtypes = [_P]
     L.rtc_scene_dump_leaves.argtypes = [_P, _dp, C.c_int]
     L.rtc_scene_bvh_info.argtypes = [_P, C.POINTER(C.c_longlong)]
+    L.rtc_scene_dump_bvh.argtypes = [_P, _P, C.c_int, _P, _P, C.c_int]
     L.rtc_first_hit_f64.argtypes = [_P, _dp, C.c_size_t, C.c_double, C.c_double, _P, _dp, _dp]
     L.rtc_first_hit_f32.argtypes = [_P, _dp, C.c_size_t, C.c_double, C.c_double, _P, _P]
     L.rtc_primary_first_hit_f64.argtypes = [_P, _P, _dp, _dp, C.c_size_t, C.c_double, C.c_double, _P, _dp, _dp]
@@ -209,6 +210,17 @@ class Scene:
         out = (C.c_longlong * 4)()
         _check(lib().rtc_scene_bvh_info(self.handle, out), "rtc_scene_bvh_info")
         return dict(nodes=out[0], leaf_slots=out[1], depth=out[2], bytes=out[3])
+
+    def dump_bvh(self):
+        """(nodes uint32[n, 16], leaves uint32[m, 8], prim_of_slot int32[m]); view the float fields with .view(np.float32)."""
+        info = self.bvh_info()
+        nodes = np.zeros((max(info["nodes"], 1), 16), dtype=np.uint32)
+        leaves = np.zeros((max(info["leaf_slots"], 1), 8), dtype=np.uint32)
+        prims = np.zeros(max(info["leaf_slots"], 1), dtype=np.int32)
+        n = lib().rtc_scene_dump_bvh(self.handle, nodes.ctypes.data, info["nodes"], leaves.ctypes.data, prims.ctypes.data, info["leaf_slots"])
+        if n < 0:
+            raise RtcError("rtc_scene_dump_bvh: " + lib().rtc_last_error().decode())
+        return nodes[:info["nodes"]], leaves[:n], prims[:n]
 
     def first_hit(self, rays7, tmin=0.001, tmax=np.inf, want_rec=False):
         rays7 = np.ascontiguousarray(rays7, dtype=np.float64)

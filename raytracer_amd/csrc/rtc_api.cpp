@@ -3,6 +3,7 @@
 // There is deliberately no CPU path here: without a usable HIP device every compute entry point fails.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <cstring>
@@ -193,6 +194,17 @@ int rtc_scene_bvh_info(const rtc_scene *scene, long long *out4) {
     out4[0] = (long long)fs.nodes.size(); out4[1] = (long long)fs.bleaves.size(); out4[2] = fs.bvh_depth;
     out4[3] = (long long)(fs.nodes.size() * sizeof(BvhNode) + fs.bleaves.size() * (sizeof(BLeaf) + sizeof(int)));
     return RTC_OK;
+}
+
+int rtc_scene_dump_bvh(const rtc_scene *scene, void *nodes16, int node_cap, void *leaves8, int *prim_of_slot, int leaf_cap) {
+    if (!scene) return fail(RTC_ERR_ARG, "rtc_scene_dump_bvh: null scene");
+    const FlatScene &fs = scene->flat;
+    static_assert(sizeof(BvhNode) == 64 && sizeof(BLeaf) == 32, "table layout");
+    if (nodes16) std::memcpy(nodes16, fs.nodes.data(), std::min((size_t)(node_cap > 0 ? node_cap : 0), fs.nodes.size()) * sizeof(BvhNode));
+    const size_t nl = std::min((size_t)(leaf_cap > 0 ? leaf_cap : 0), fs.bleaves.size());
+    if (leaves8) std::memcpy(leaves8, fs.bleaves.data(), nl * sizeof(BLeaf));
+    if (prim_of_slot) std::memcpy(prim_of_slot, fs.leaf_prims.data(), nl * sizeof(int));
+    return (int)fs.bleaves.size();
 }
 
 static int ensure_f64(rtc_scene *s) {

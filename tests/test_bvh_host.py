@@ -1,0 +1,138 @@
+"""CPU: the host half of the production BVH (flatten.cpp: binned-SAH builder, 32-byte world-space traversal leaves), checked
+without a GPU through rtc_scene_flatten_only + rtc_scene_dump_bvh.
+
+ * structure: every leaf slot is referenced by exactly one leaf run, every inner node by exactly one parent, the depth
+   reported by rtc_scene_bvh_info bounds every root-to-leaf path, child boxes contain the geometry below them;
+ * geometry: a numpy brute-force closest hit over the dumped FP32 leaves (spheres, moving spheres, rects: what the HIP
+   traversal tests) agrees with the oracle's list scan (hittable_list.c:125-143) on the same rays -- same primitive, t
+   within 1e-4 relative (FP32 tables against the FP64 oracle).  Media are skipped on both sides.
+"""
+import numpy as np
+import pytest
+
+EMPTY = -(2 ** 31)
+
+
+def decode(child):
+    v = ~int(child)
+    return v >> 3, (v & 7) + 1
+
+
+def walk(nodes_i, nodes_f, n_leaves):
+    """-> (leaf reference count per slot, node reference count, max depth, per-slot list of enclosing boxes)"""
+    leaf_refs = np.zeros(n_leaves, dtype=np.int64)
+    node_refs = np.zeros(len(nodes_i), dtype=np.int64)
+    boxes = [None] * n_leaves
+    max_depth = 0
+    stack = [(0, 1)]
+    node_refs[0] = 1
+    while stack:
+        n, depth = stack.pop()
+        max_depth = max(max_depth, depth)
+        for side in (0, 1):
+            child = int(nodes_i[n, 3 + 8 * side])
+            lo, hi = nodes_f[n, 8 * side:8 * side + 3], nodes_f[n, 8 * side + 4:8 * side + 7]
+            if child == EMPTY:
+                continue
+            if child >= 0:
+                node_refs[child] += 1
+                stack.append((child, depth + 1))
+            else:
+                first, count = decode(child)
+                assert count == int(nodes_i[n, 7 + 8 * side])
+                max_depth = max(max_depth, depth + 1)
+                for s in range(first, first + count):
+                    leaf_refs[s] += 1
+                    boxes[s] = (lo.copy(), hi.copy())
+    return leaf_refs, node_refs, max_depth, boxes
+
+
+def brute_force(leaves_u, prims, rays, tmin=1e-3):
+    """Closest hit over all traversal leaves in float64 arithmetic on the FP32 table values; ties -> highest primitive id."""
+    lf = leaves_u.view(np.float32).astype(np.float64)
+    meta = leaves_u[:, 7]
+    o, d, tm = rays[:, None, 0:3], rays[:, None, 3:6], rays[:, None, 6]
+    n, m = len(rays), len(lf)
+    t_all = np.full((n, m), np.inf)
+    typ = meta & 3
+    # spheres / moving spheres
+    for kind in (0, 1):
+        idx = np.nonzero(typ == kind)[0]
+        if not len(idx):
+            continue
+        L = lf[idx]
+        c = L[None, :, 0:3] + (L[None, :, 3:6] * tm[..., None] if kind == 1 else 0.0)
+        r = L[None, :, 6] if kind == 1 else L[None, :, 3]
+        oc = o - c
+        a = (d * d).sum(-1)
+        hb = (oc * d).sum(-1)
+        cc = (oc * oc).sum(-1) - r * r
+        disc = hb * hb - a * cc
+        sq = np.sqrt(np.maximum(disc, 0))
+        t0, t1 = (-hb - sq) / a, (-hb + sq) / a
+        t = np.where(t0 >= tmin, t0, np.where(t1 >= tmin, t1, np.inf))
+        t_all[:, idx] = np.where(disc >= 0, t, np.inf)
+    idx = np.nonzero(typ == 2)[0]
+    if len(idx):
+        assert (meta[idx] >> 12 == 0).all(), "this check only handles rects in world space"
+        L = lf[idx]
+        axis = (meta[idx] >> 2) & 3                              # XY, XZ, YZ
+        nrm = np.array([2, 1, 0])[axis]
+        ia = np.array([0, 0, 1])[axis]
+        ib = np.array([1, 2, 2])[axis]
+        on, dn = np.take_along_axis(o[:, 0], nrm[None, :].repeat(n, 0), 1), np.take_along_axis(d[:, 0], nrm[None, :].repeat(n, 0), 1)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            t = (L[None, :, 0] - on) / dn
+        pa = np.take_along_axis(o[:, 0], ia[None, :].repeat(n, 0), 1) + t * np.take_along_axis(d[:, 0], ia[None, :].repeat(n, 0), 1)
+        pb = np.take_along_axis(o[:, 0], ib[None, :].repeat(n, 0), 1) + t * np.take_along_axis(d[:, 0], ib[None, :].repeat(n, 0), 1)
+        ok = (t >= tmin) & (pa >= L[None, :, 1]) & (pa <= L[None, :, 3]) & (pb >= L[None, :, 2]) & (pb <= L[None, :, 4])
+        t_all[:, idx] = np.where(ok, t, np.inf)
+    best = t_all.min(axis=1)
+    tie = np.isclose(t_all, best[:, None], rtol=1e-12, atol=0) & np.isfinite(t_all)
+    prim = np.where(tie, prims[None, :], -1).max(axis=1)
+    return np.where(np.isfinite(best), prim, -1), best
+
+
+@pytest.mark.parametrize("name,arg", [("book1", 0), ("final", 0), ("book2_random", 0), ("million", 40)])
+def test_bvh_structure_and_leaf_geometry(rtc, oracle_lib, name, arg):
+    sc, cam, view = rtc.build_named_scene(name, arg=arg, host_only=True)
+    try:
+        info = sc.bvh_info()
+        nodes_u, leaves_u, prims = sc.dump_bvh()
+        assert info["nodes"] == len(nodes_u) > 0 and info["leaf_slots"] == len(leaves_u) == sc.num_prims()
+        assert sorted(prims.tolist()) == list(range(sc.num_prims()))       # a permutation: slot -> primitive id
+        nodes_i, nodes_f = nodes_u.view(np.int32), nodes_u.view(np.float32)
+        leaf_refs, node_refs, depth, boxes = walk(nodes_i, nodes_f, len(leaves_u))
+        assert (leaf_refs == 1).all() and (node_refs == 1).all()
+        assert depth <= info["depth"] <= 64
+        lf = leaves_u.view(np.float32)
+        typ = leaves_u[:, 7] & 3
+        for s in np.nonzero(typ == 0)[0][:500]:                              # spheres: centre +- r inside the parent's child box
+            lo, hi = boxes[s]
+            c, r = lf[s, 0:3], abs(lf[s, 3])
+            assert (c - r >= lo - 1e-3).all() and (c + r <= hi + 1e-3).all()
+        # geometry of the leaves against the oracle
+        o = oracle_lib
+        o.set_stage(3)
+        o.build(name, arg=arg)
+        g = np.stack(np.meshgrid((np.arange(40) + .5) / 39, (np.arange(24) + .5) / 23), -1).reshape(-1, 2)
+        rays = o.camera_rays(g, seed=5)
+        rec, prim_ref = o.hit_rays(rays)
+        keep = rec[:, 11] != 4                                               # the oracle hit a medium: stochastic, skipped
+        prim, t = brute_force(leaves_u, prims, rays)
+        assert (prim[keep] == prim_ref[keep]).mean() >= 0.995                # FP32 table values: a grazing ray may flip
+        same = keep & (prim == prim_ref) & (prim_ref >= 0)
+        assert same.sum() > 200
+        assert np.abs(t[same] - rec[same, 1]).max() <= 1e-4 * np.maximum(1.0, rec[same, 1]).max()
+    finally:
+        sc.close()
+
+
+def test_small_scenes_have_no_bvh(rtc):
+    sc, cam, view = rtc.build_named_scene("cornell", host_only=True)
+    try:
+        assert sc.bvh_info() == dict(nodes=0, leaf_slots=0, depth=0, bytes=0)
+        nodes, leaves, prims = sc.dump_bvh()
+        assert len(nodes) == 0 and len(leaves) == 0
+    finally:
+        sc.close()

@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -293,7 +294,16 @@ static int render_wavefront(rtc_scene *s, const CameraT<float> &camf, const Rend
     const int spp = p.s_end - p.s_begin;
     if (spp <= 0) return RTC_OK;
     const long long per_layer = (long long)p.n_tiles * 64;
-    long long layers = ((1ll << 20) + per_layer - 1) / per_layer;      // aim at >= 1M slots in flight
+    // Slots per pixel ("layers").  A slot walks through its samples one after the other, so a render lasts as many bounces
+    // as the UNLUCKIEST slot needs; with ~8 samples per slot that is <= 8 * max_depth bounces of large launches instead of
+    // hundreds of bounces whose tail runs on a few live slots (final scene 1024^2 x 256 spp: 411 ms at 1M slots, 227 ms at
+    // 32M).  Past ~32M slots (3 GB of state) the footprint costs more than the shorter tail gains.  RTC_WF_SLOTS overrides
+    // the cap for experiments.
+    long long max_slots = 32ll << 20;
+    if (const char *e = std::getenv("RTC_WF_SLOTS")) { const long long v = std::atoll(e); if (v > 0) max_slots = v; }
+    long long layers = (spp + 7) / 8;
+    if (layers * per_layer > max_slots) layers = max_slots / per_layer;
+    if (layers * per_layer < (1ll << 20)) layers = ((1ll << 20) + per_layer - 1) / per_layer;   // small images: at least 1M slots
     if (layers > spp) layers = spp;
     if (layers < 1) layers = 1;
     const long long n_slots = per_layer * layers;

@@ -163,7 +163,8 @@ RT_DEV f3 small_light_sample(const SceneT<float> &sc, int pick, f3 o, float r1, 
 template <int INTEGRATOR, bool PROBE>
 __global__ void __launch_bounds__(256) k_pathtrace_small(SmallScene ss, SceneT<float> sc, CameraT<float> cam, RenderParams P,
                                                           float4 *__restrict__ accum, unsigned long long *__restrict__ counters,
-                                                          const int *__restrict__ tile_perm, int *__restrict__ tile_cost) {
+                                                          const int *__restrict__ tile_perm, int *__restrict__ tile_cost,
+                                                          float4 *__restrict__ partial, int log2_chunks) {
     __shared__ SmallShade lds_shade[RTC_SMALL_MAX_LEAVES];
     {   // 48 B x n_leaves, copied dword by dword
         const uint32_t *src = (const uint32_t *)ss.shade;
@@ -172,9 +173,14 @@ __global__ void __launch_bounds__(256) k_pathtrace_small(SmallScene ss, SceneT<f
     }
     __syncthreads();
     const int lane = threadIdx.x & 63;
-    int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (tile >= P.n_tiles) return;   // wave-uniform, after the only barrier
+    // work item = (tile, chunk of the sample range): 2^log2_chunks waves share a tile, each with its own samples
+    const int item = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (item >= (P.n_tiles << log2_chunks)) return;   // wave-uniform, after the only barrier
+    int tile = item >> log2_chunks;
+    const int chunk = item & ((1 << log2_chunks) - 1);
     if (!PROBE && tile_perm) tile = tile_perm[tile];   // heaviest tiles first (launch_pathtrace_small)
+    const int spp_all = P.s_end - P.s_begin, q = spp_all >> log2_chunks, r = spp_all & ((1 << log2_chunks) - 1);
+    const int s_lo = P.s_begin + chunk * q + (chunk < r ? chunk : r), s_hi = s_lo + q + (chunk < r ? 1 : 0);
     const int px = (tile % P.tiles_x) * 8 + (lane & 7), py = (tile / P.tiles_x) * 8 + (lane >> 3);
     const bool valid = px < P.width && py < P.height;
     const uint32_t pixel = (uint32_t)(py * P.width + px);
@@ -183,13 +189,13 @@ __global__ void __launch_bounds__(256) k_pathtrace_small(SmallScene ss, SceneT<f
 
     f3 sum = f3mk(0, 0, 0), T = f3mk(1, 1, 1), L = f3mk(0, 0, 0), ro = f3mk(0, 0, 0), rd = f3mk(0, 0, 1);
     unsigned nrays = 0, iters = 0;
-    int s_next = P.s_begin, depth = 0, src = -1;
+    int s_next = s_lo, depth = 0, src = -1;
     uint32_t s_cur = 0;
     bool alive = false;
 
     for (;;) {
         if (P.max_depth <= 0) break;                                       // ray.c:52
-        if (!alive && valid && s_next < P.s_end) {                         // main.c:150-152 + camera.c:46-53
+        if (!alive && valid && s_next < s_hi) {                            // main.c:150-152 + camera.c:46-53
             s_cur = (uint32_t)s_next++;
             const Rng4 c = rng_block(pixel, s_cur, RT_TAG_CAMERA, P.seed_lo, P.seed_hi);
             const float u = ((float)px + c.x) * inv_w, v = ((float)py + c.y) * inv_h;
@@ -279,11 +285,22 @@ __global__ void __launch_bounds__(256) k_pathtrace_small(SmallScene ss, SceneT<f
     for (int off = 32; off > 0; off >>= 1) total += __shfl_xor(total, off, 64);
     if (PROBE) { if (lane == 0) tile_cost[tile] = (int)total; return; }   // cost probe: rays of this tile, nothing else is written
     if (valid) {
-        float4 a = accum[pixel];
-        a.x += sum.x; a.y += sum.y; a.z += sum.z; a.w += (float)(P.s_end - P.s_begin);
-        accum[pixel] = a;
+        if (log2_chunks == 0) {                                            // the only wave of this pixel: straight into the accumulator
+            float4 a = accum[pixel];
+            a.x += sum.x; a.y += sum.y; a.z += sum.z; a.w += (float)(s_hi - s_lo);
+            accum[pixel] = a;
+        } else partial[(size_t)chunk * ((size_t)P.width * P.height) + pixel] = make_float4(sum.x, sum.y, sum.z, (float)(s_hi - s_lo));
     }
     if (lane == 0) { atomicAdd(counters, (unsigned long long)total); atomicAdd(counters + 1, (unsigned long long)iters); }
+}
+
+// accum += the partial sums of a pixel's chunks, in chunk order: the result does not depend on which wave finished first
+__global__ void __launch_bounds__(256) k_small_combine(const float4 *__restrict__ partial, int n_pixels, int chunks, float4 *__restrict__ accum) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_pixels) return;
+    float4 a = accum[i];
+    for (int c = 0; c < chunks; ++c) { const float4 s = partial[(size_t)c * n_pixels + i]; a.x += s.x; a.y += s.y; a.z += s.z; a.w += s.w; }
+    accum[i] = a;
 }
 
 // Tiles sorted by descending cost (rays of a one-sample probe): counting sort in one workgroup.  The order inside a cost
@@ -303,29 +320,37 @@ __global__ void __launch_bounds__(1024) k_tile_order(const int *__restrict__ cos
 
 template <bool PROBE>
 static void launch_small(const SmallScene &ss, const SceneT<float> &sc, const CameraT<float> &cam, const RenderParams &p, float4 *accum,
-                         unsigned long long *counters, const int *perm, int *cost, hipStream_t stream) {
-    const unsigned blocks = (unsigned)((p.n_tiles + 3) / 4);
-    if (p.integrator == 0) hipLaunchKernelGGL((k_pathtrace_small<0, PROBE>), dim3(blocks), dim3(256), 0, stream, ss, sc, cam, p, accum, counters, perm, cost);
-    else if (p.integrator == 1) hipLaunchKernelGGL((k_pathtrace_small<1, PROBE>), dim3(blocks), dim3(256), 0, stream, ss, sc, cam, p, accum, counters, perm, cost);
-    else hipLaunchKernelGGL((k_pathtrace_small<2, PROBE>), dim3(blocks), dim3(256), 0, stream, ss, sc, cam, p, accum, counters, perm, cost);
+                         unsigned long long *counters, const int *perm, int *cost, float4 *partial, int log2_chunks, hipStream_t stream) {
+    const unsigned blocks = (unsigned)((((long long)p.n_tiles << log2_chunks) + 3) / 4);
+    if (p.integrator == 0) hipLaunchKernelGGL((k_pathtrace_small<0, PROBE>), dim3(blocks), dim3(256), 0, stream, ss, sc, cam, p, accum, counters, perm, cost, partial, log2_chunks);
+    else if (p.integrator == 1) hipLaunchKernelGGL((k_pathtrace_small<1, PROBE>), dim3(blocks), dim3(256), 0, stream, ss, sc, cam, p, accum, counters, perm, cost, partial, log2_chunks);
+    else hipLaunchKernelGGL((k_pathtrace_small<2, PROBE>), dim3(blocks), dim3(256), 0, stream, ss, sc, cam, p, accum, counters, perm, cost, partial, log2_chunks);
 }
 
-// tile_scratch: 2 * n_tiles ints (cost, order) or NULL.  A wave owns a tile for all samples of the launch, and an interior
-// Cornell tile costs 5x a border tile (8.5 ms of a 37 ms launch at 1080p x 256 spp): with tiles in image order the last
-// heavy tiles run on a nearly empty GPU.  A one-sample probe measures every tile's rays, the tiles are sorted, and the main
-// launch takes them heaviest first, so the tail is made of the cheapest tiles (37.5 -> 33 ms).
+// tile_scratch: 2 * n_tiles ints (cost, order) or NULL.  A wave owns a tile for its samples of the launch, and an interior
+// Cornell tile costs 5x a border tile: with tiles in image order the last heavy tiles run on a nearly empty GPU.
+//  * A one-sample probe measures every tile's rays, the tiles are sorted, and the main launch takes them heaviest first, so
+//    the tail is made of the cheapest tiles (1080p x 256 spp: 37.5 -> 33.5 ms).
+//  * partial (2^log2_chunks * W * H float4, or NULL): the sample range of a tile is split over 2^log2_chunks waves whose
+//    sums go to their own plane and are added in a fixed order afterwards -- four times finer work items for 0.1 ms of
+//    extra HBM traffic, and still no atomics on radiance.
 hipError_t launch_pathtrace_small(const SmallScene &ss, const SceneT<float> &sc, const CameraT<float> &cam, const RenderParams &p,
-                                  float4 *accum, unsigned long long *counters, int *tile_scratch, hipStream_t stream) {
+                                  float4 *accum, unsigned long long *counters, int *tile_scratch, float4 *partial, int log2_chunks, hipStream_t stream) {
     if (p.n_tiles <= 0 || p.s_end <= p.s_begin) return hipSuccess;
     if (ss.n_leaves <= 0 || ss.n_leaves > RTC_SMALL_MAX_LEAVES) return hipErrorInvalidValue;
+    if (!partial) log2_chunks = 0;
     const int *perm = nullptr;
     if (tile_scratch && p.s_end - p.s_begin >= 32 && p.n_tiles >= 2048 && p.max_depth > 0) {
         RenderParams probe = p; probe.s_end = probe.s_begin + 1;
         int *cost = tile_scratch, *order = tile_scratch + p.n_tiles;
-        launch_small<true>(ss, sc, cam, probe, accum, counters, nullptr, cost, stream);
+        launch_small<true>(ss, sc, cam, probe, accum, counters, nullptr, cost, nullptr, 0, stream);
         hipLaunchKernelGGL(k_tile_order, dim3(1), dim3(1024), 0, stream, cost, p.n_tiles, order);
         perm = order;
     }
-    launch_small<false>(ss, sc, cam, p, accum, counters, perm, nullptr, stream);
+    launch_small<false>(ss, sc, cam, p, accum, counters, perm, nullptr, partial, log2_chunks, stream);
+    if (log2_chunks > 0) {
+        const int n_pixels = p.width * p.height;
+        hipLaunchKernelGGL(k_small_combine, dim3((unsigned)((n_pixels + 255) / 256)), dim3(256), 0, stream, partial, n_pixels, 1 << log2_chunks, accum);
+    }
     return hipGetLastError();
 }

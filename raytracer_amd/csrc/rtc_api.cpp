@@ -106,6 +106,7 @@ struct rtc_scene {
     DeviceTables<double> f64;
     DevBuf ray_counter;
     DevBuf tile_scratch; size_t tile_scratch_cap = 0;   // small-scene kernel: cost + order of the 8x8 tiles
+    DevBuf small_partial; size_t small_partial_cap = 0; // small-scene kernel: per-chunk partial sums (float4 per pixel and chunk)
     DevBuf wf_pool; size_t wf_slots_cap = 0;   // wavefront path-slot state, grown on demand
     DevBuf small_pairs, small_groups, small_spheres, small_shade, small_xforms, small_boxes;
     SmallScene small{};   // n_leaves == 0: not eligible
@@ -380,7 +381,21 @@ int rtc_render_device(const rtc_scene *scene_c, const camera *cam, const rtc_set
             if (hipMalloc(&s->tile_scratch.p, 2 * (size_t)p.n_tiles * sizeof(int)) == hipSuccess) s->tile_scratch_cap = (size_t)p.n_tiles;
             else s->tile_scratch.p = nullptr;                       // no scratch: tiles run in image order
         }
-        HIP_TRY(launch_pathtrace_small(s->small, s->f32.view, camf, p, (float4 *)accum_dev, (unsigned long long *)s->ray_counter.p, (int *)s->tile_scratch.p, stream));
+        // split a tile's samples over several waves until there are ~60K work items (12 per resident wave slot), keeping at
+        // least 32 samples per wave: finer items shorten the tail of the launch, but every wave pays its own ramp-down
+        // (measured at 1080p x 256 spp: 1 wave per tile 30.9 ms, 2 waves 29.4, 4 waves 29.9, 8 waves 32.8)
+        int log2_chunks = 0;
+        const int spp = p.s_end - p.s_begin;
+        while (log2_chunks < 3 && ((long long)p.n_tiles << log2_chunks) < 60000 && (spp >> (log2_chunks + 1)) >= 32) ++log2_chunks;
+        if (const char *e = std::getenv("RTC_SMALL_LOG2_CHUNKS")) { const int v = std::atoi(e); if (v >= 0 && v <= 3 && (spp >> v) >= 1) log2_chunks = v; }   // tuning knob
+        const size_t need = log2_chunks ? ((size_t)p.width * p.height) << log2_chunks : 0;
+        if (need > s->small_partial_cap) {
+            if (s->small_partial.p) { HIP_TRY(hipStreamSynchronize(stream)); (void)hipFree(s->small_partial.p); s->small_partial.p = nullptr; s->small_partial_cap = 0; }
+            if (hipMalloc(&s->small_partial.p, need * sizeof(float4)) == hipSuccess) s->small_partial_cap = need;
+            else { s->small_partial.p = nullptr; log2_chunks = 0; }   // no scratch: one wave per tile
+        }
+        HIP_TRY(launch_pathtrace_small(s->small, s->f32.view, camf, p, (float4 *)accum_dev, (unsigned long long *)s->ray_counter.p, (int *)s->tile_scratch.p,
+                                       log2_chunks ? (float4 *)s->small_partial.p : nullptr, log2_chunks, stream));
     }
     else if (wavefront) { rc = render_wavefront(s, camf, p, (float4 *)accum_dev, stream); if (rc) return rc; }
     else HIP_TRY(launch_pathtrace_mega(s->f32.view, camf, p, (float4 *)accum_dev, (unsigned long long *)s->ray_counter.p, stream));

@@ -288,3 +288,23 @@ def test_wavefront_sample_ranges_layers_and_refusal(gpu):
             sc.render(cam, gpu.Settings(16, 16, 1, 10, 0, kernel=3))
     finally:
         sc.close()
+
+
+def test_small_kernel_split_tiles_are_deterministic(gpu):
+    """At >= 64 spp the small-scene kernel splits a tile's samples over several waves (partial sums per chunk, added in a
+    fixed order) and runs the tiles heaviest first (one-sample probe + device sort, >= 2048 tiles).  Neither may change the
+    image from run to run, and the chunked sum must agree with the same samples rendered range by range."""
+    sc, cam, view = gpu.build_named_scene("cornell")
+    try:
+        W, H, spp = 512, 384, 128                                  # 3072 tiles -> probe + sort; 128 spp -> 2 or 4 chunks
+        a, sa = sc.render(cam, gpu.Settings(W, H, spp, 10, 0, seed=4))
+        b, sb = sc.render(cam, gpu.Settings(W, H, spp, 10, 0, seed=4))
+        assert sa["kernel_used"] == 2 and np.array_equal(a, b) and sa["rays"] == sb["rays"]
+        assert (a[..., 3] == spp).all()
+        acc = np.zeros((H, W, 4), dtype=np.float32)
+        for lo, hi in ((0, 16), (16, 17), (17, 128)):              # small ranges run unsplit, the large one split
+            acc, _ = sc.render(cam, gpu.Settings(W, H, 0, 10, 0, seed=4, sample_begin=lo, sample_end=hi), accum=acc)
+        assert (acc[..., 3] == spp).all()
+        assert np.allclose(acc[..., :3], a[..., :3], rtol=2e-5, atol=1e-5)
+    finally:
+        sc.close()

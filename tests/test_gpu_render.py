@@ -308,3 +308,54 @@ def test_small_kernel_split_tiles_are_deterministic(gpu):
         assert np.allclose(acc[..., :3], a[..., :3], rtol=2e-5, atol=1e-5)
     finally:
         sc.close()
+
+
+def test_full_size_cornell_1080p_matches_the_fixture_statistics(gpu):
+    """BASELINE config 2 at its full size (1920x1080, aspect 16/9, depth 10; 64 spp to keep the test short), checked through
+    size-independent properties against the 240x135 high-spp fixture of the same view: every pixel gets exactly spp
+    finite samples; mean luminance within 2 % (the 240-pixel image spans u in [0, 240/239], the 1920-pixel one [0, 1920/1919]:
+    0.8 % more black border in the fixture); both images averaged over a 15x8 grid of blocks (128x128 pixels here,
+    16x16 fixture pixels) agree within RMSE 0.01.  (Pixel-level comparison is not meaningful: u = (i + xi) / (W - 1) makes
+    the two pixel grids drift apart by up to one fixture pixel across the image.)"""
+    fx = golden("image_cornell_16x9_240.npz")
+    ref = clip01(fx["mean"].astype(np.float64))
+    sc, cam, view = gpu.build_named_scene("cornell", aspect=16 / 9)
+    try:
+        acc, st = sc.render(cam, gpu.Settings(1920, 1080, 64, 10, 0, seed=77))
+    finally:
+        sc.close()
+    assert st["samples"] == 1920 * 1080 * 64 and st["kernel_used"] == 2
+    assert (acc[..., 3] == 64).all() and np.isfinite(acc).all()
+    img = clip01(mean_image(acc))
+    coarse = img[:1024].reshape(8, 128, 15, 128, 3).mean(axis=(1, 3))
+    coarse_ref = ref[:128].reshape(8, 16, 15, 16, 3).mean(axis=(1, 3))
+    rmse = np.sqrt(((coarse - coarse_ref) ** 2).mean(axis=(0, 1)))
+    la, lb = (img @ LUMA).mean(), (ref @ LUMA).mean()
+    print(f"1080p vs fixture: rmse {rmse.round(5)} dlum {abs(la - lb) / lb:.5f} rays/sample {st['rays'] / st['samples']:.3f}")
+    assert rmse.max() <= 0.01 and abs(la - lb) / lb <= 0.02
+    assert abs(st["rays"] / st["samples"] - float(fx["rays_per_sample"])) <= 0.05 * float(fx["rays_per_sample"])
+
+
+def test_full_size_million_spheres(gpu):
+    """BASELINE config 5 at its full size (1,000,004 spheres): the FP32 production traversal agrees with the bit-exact FP64
+    kernel on the primary rays of a 192x108 grid (same primitive for >= 99.5 %), the BVH keeps its depth bound, and the
+    wavefront and megakernel renders (same Philox keys) agree: block RMSE <= 0.002, rays per sample within 0.5 %."""
+    sc, cam, view = gpu.build_named_scene("million", arg=1000)
+    try:
+        info = sc.bvh_info()
+        assert sc.num_prims() == 1000004 and info["leaf_slots"] == 1000004 and 0 < info["depth"] <= 64
+        g = np.stack(np.meshgrid((np.arange(192) + .5) / 191, (np.arange(108) + .5) / 107), -1).reshape(-1, 2)
+        lens = np.zeros((len(g), 3))
+        prim, t, rays = sc.primary_first_hit(cam, g, lens)
+        rays = rays.astype(np.float32).astype(np.float64)
+        p64, t64 = sc.first_hit(rays)
+        p32, t32 = sc.first_hit_f32(rays)
+        assert (p64 >= 0).mean() > 0.5 and (p32 == p64).mean() >= 0.995
+        W, H, spp = 480, 270, 32
+        a, sa = sc.render(cam, gpu.Settings(W, H, spp, view.max_depth, view.integrator, seed=5, kernel=1))
+        b, sb = sc.render(cam, gpu.Settings(W, H, spp, view.max_depth, view.integrator, seed=5, kernel=3))
+    finally:
+        sc.close()
+    ia, ib = clip01(mean_image(a)), clip01(mean_image(b))
+    blk = np.sqrt(((block_means(ia) - block_means(ib)) ** 2).mean(axis=(0, 1)))
+    assert blk.max() <= 0.002 and abs(sa["rays"] - sb["rays"]) <= 0.005 * sa["rays"]

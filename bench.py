@@ -41,6 +41,11 @@ SPP_PER_GPU = 256
 ALGO_FLOP_PER_RAY = 218.6
 PEAK_FP32_VALU_TFLOPS = 157.3     # MI355X_MICROARCH.md: 256 CU x 4 SIMD x 32 lanes x 2 (FMA) x 2.4 GHz
 ALGO_HBM_BYTES_PER_PIXEL = 32     # float4 accumulator read + write once per launch
+PEAK_L2_GBS = 34500.0             # MI355X_MICROARCH.md: 8 x 4 MiB L2, ~34.5 TB/s aggregate (HBM3E: 8 TB/s)
+# BVH scenes (wavefront kernels): measured traversal steps per ray (probe builds RT_EXP=3/4) ->
+# algorithmic bytes per ray = node steps x 64 B + leaf steps x 36 B (32-B leaf + its primitive id) + 232 B of path-slot state
+SCENE_BYTES = {"final": 13.0 * 64 + 4.8 * 36 + 232, "final_earth": 13.0 * 64 + 4.8 * 36 + 232, "book1": 8.7 * 64 + 3.8 * 36 + 232,
+               "million": 22.7 * 64 + 4.4 * 36 + 232}
 
 
 def measured_traffic():
@@ -97,6 +102,9 @@ def main():
     ap.add_argument("--width", type=int, default=WIDTH, help="image width (BASELINE config 4: --width 3840 --height 2160 --spp 2048 on 8 GPUs)")
     ap.add_argument("--height", type=int, default=HEIGHT)
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--scene", default="cornell", choices=sorted(SCENE_BYTES) + ["cornell"],
+                    help="cornell = BASELINE config 2/4 (default, the headline line); final / final_earth = config 3; million = config 5; "
+                         "book1 = config 1 on the GPU.  The CPU leg and the committed PMC traffic only exist for cornell")
     ap.add_argument("--png", default="", help="write the last frame here (rank 0)")
     a = ap.parse_args()
     WIDTH, HEIGHT = a.width, a.height
@@ -114,7 +122,9 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     ra.rtc_init()                                                # raises without a gfx950 GPU: there is no CPU fallback
 
-    scene, cam, view = ra.build_named_scene("cornell", aspect=WIDTH / HEIGHT)
+    cornell = a.scene == "cornell"
+    scene, cam, view = ra.build_named_scene(a.scene, arg=1000 if a.scene == "million" else 0, aspect=WIDTH / HEIGHT)
+    depth = DEPTH if cornell else view.max_depth
     accum = rdist.new_accum(HEIGHT, WIDTH, dev)
     rgb8 = torch.empty((HEIGHT, WIDTH, 3), dtype=torch.uint8, device=dev)
     kernel_ms, rays_total, kernel_used, lane_fill = [], 0, [0], [0.0]
@@ -123,7 +133,7 @@ def main():
         nonlocal rays_total
         begin, end = rdist.shard_samples(a.spp * world, rank, world, base=i * a.spp * world)
         accum.zero_()
-        stream = rdist.render_into(scene, cam, ra.Settings(WIDTH, HEIGHT, 0, DEPTH, 0, seed=0, sample_begin=begin, sample_end=end), accum)
+        stream = rdist.render_into(scene, cam, ra.Settings(WIDTH, HEIGHT, 0, depth, view.integrator, seed=0, sample_begin=begin, sample_end=end), accum)
         rdist.reduce_accum(accum, dst=0)                         # one collective per frame (RCCL over xGMI); no-op at N=1
         if rank == 0:
             rc = ra.lib().rtc_tonemap_u8_device(accum.data_ptr(), WIDTH, HEIGHT, rgb8.data_ptr(), stream)
@@ -163,14 +173,17 @@ def main():
         samples_all = WIDTH * HEIGHT * a.spp * world * a.steps
         rays_per_launch = rays_all / max(1, a.steps * world)
         achieved = ALGO_FLOP_PER_RAY * rays_per_launch / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
-        traffic = measured_traffic() if (WIDTH, HEIGHT, a.spp) == (1920, 1080, SPP_PER_GPU) else None   # the committed PMC passes ran the default workload
+        traffic = measured_traffic() if (cornell, WIDTH, HEIGHT, a.spp) == (True, 1920, 1080, SPP_PER_GPU) else None   # the committed PMC passes ran the default workload
+        workload = ("03_FullTracer Cornell box (setupScene), mixture-PDF light/glass-sphere importance sampling" if cornell else
+                    {"final": "02_AdvancedTracer final scene", "final_earth": "02_AdvancedTracer final scene + earth-map globe",
+                     "book1": "01_BasicTracer Book-1 random spheres", "million": "synthetic 1,000,004-sphere scene"}[a.scene])
         line = {
-            "metric": "Msamples/sec (whole node) @1080p Cornell box", "value": samples_all / elapsed / 1e6, "unit": "Msamples/s",
+            "metric": "Msamples/sec (whole node) @1080p Cornell box" if cornell else f"Msamples/sec (whole node), scene {a.scene}",
+            "value": samples_all / elapsed / 1e6, "unit": "Msamples/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed / max(1, a.steps) * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "03_FullTracer Cornell box (setupScene), mixture-PDF light/glass-sphere importance sampling, "
-                                   f"{WIDTH}x{HEIGHT}, camera aspect {WIDTH / HEIGHT:.4g}, depth {DEPTH}, {a.spp} spp per GPU per step",
-                       "width": WIDTH, "height": HEIGHT, "spp_per_gpu": a.spp, "global_spp": a.spp * world, "max_depth": DEPTH,
+            "config": {"workload": f"{workload}, {WIDTH}x{HEIGHT}, camera aspect {WIDTH / HEIGHT:.4g}, depth {depth}, {a.spp} spp per GPU per step",
+                       "width": WIDTH, "height": HEIGHT, "spp_per_gpu": a.spp, "global_spp": a.spp * world, "max_depth": depth,
                        "sharding": f"samples/{world}", "collective": "reduce(sum) of float4[W*H] to rank 0" if world > 1 else "none"},
             "mrays_per_s": rays_all / elapsed / 1e6, "rays_per_sample": rays_all / samples_all,
             "roofline": {"bound": "valu", "achieved": achieved, "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s",
@@ -180,7 +193,14 @@ def main():
                          "algorithmic_flop_per_ray": ALGO_FLOP_PER_RAY,
                          "algorithmic_hbm_bytes_per_launch": ALGO_HBM_BYTES_PER_PIXEL * WIDTH * HEIGHT},
         }
-        if world == 1 and not a.no_cpu:
+        if not cornell:
+            # BVH scenes: the tree (1M spheres: 56 MB) is served by the L2s and the 256 MB Infinity Cache, not by HBM (measured
+            # HBM reads: 44 MB per extend launch), so the algorithmic fetch bytes are priced against the aggregate L2 bandwidth
+            gbs = SCENE_BYTES[a.scene] * rays_per_launch / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+            line["roofline"] = {"bound": "l2", "achieved": gbs, "peak": PEAK_L2_GBS, "unit": "GB/s", "frac": gbs / PEAK_L2_GBS, "traffic": None,
+                                "kernel": "k_wf_extend + k_wf_shade", "kernel_ms": k_ms, "rays_per_launch": rays_per_launch,
+                                "algorithmic_bytes_per_ray": SCENE_BYTES[a.scene]}
+        if world == 1 and not a.no_cpu and cornell:
             line.update(cpu_baseline())
             line["speedup_vs_cpu_baseline"] = line["value"] / line["cpu_baseline"]["value"]
         if a.png:

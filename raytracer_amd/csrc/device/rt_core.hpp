@@ -213,11 +213,26 @@ struct LdsStack {
     RT_DEV int pop() { if (sp == 0) return RTC_BVH_EMPTY; --sp; return base[sp * stride]; }
 };
 struct HitS { float t; int prim, slot; };
-// One BLeaf against the ray: candidate parameter in [tmin, tmax] as sphere_t / rect_t accept it.
+// One BLeaf against the ray: candidate parameter in [tmin, tmax] as sphere_t / rect_t accept it.  Written without early
+// returns: the leaf type is the only branch (usually wave-uniform), everything below it is selects, so the traversal
+// loop carries no nested exec masks.
+RT_DEV bool sphere_roots_f32(V3<float> c, float rad, const RayT<float> &r, float tmin, float tmax, bool from_here, float &t) {
+    // closest-approach form of line_sphere_intersection (see sphere_t<float>); a ray that starts on the sphere has the
+    // roots {0, 2 tc} (sphere_leave_t)
+    const V3<float> oc = r.o - c;
+    const float inv_a = __builtin_amdgcn_rcpf(len2(r.d));
+    const float tc = -dot(oc, r.d) * inv_a;
+    const V3<float> l = oc + r.d * tc;
+    const float q = (rad * rad - len2(l)) * inv_a;
+    const float sq = __builtin_amdgcn_sqrtf(fmaxf(q, 0.0f));
+    const float t0 = from_here ? 2.0f * tc : tc - sq, t1 = tc + sq;
+    const bool ok0 = (t0 >= tmin) & (t0 <= tmax), ok1 = (t1 >= tmin) & (t1 <= tmax) & !from_here;
+    t = ok0 ? t0 : t1;
+    return (from_here | (q >= 0.0f)) & (ok0 | ok1);
+}
 RT_DEV bool bleaf_t(const SceneT<float> &sc, const BLeaf &lf, const RayT<float> &r, float tmin, float tmax, bool from_here, float &t) {
     const uint32_t type = lf.meta & 3u;
     if (type == RTC_PRIM_RECT) {
-        if (from_here) return false;                                  // a ray cannot re-hit the plane it leaves
         V3<float> o = r.o, d = r.d;
         const uint32_t xf = lf.meta >> 12;
         if (xf) {
@@ -232,19 +247,14 @@ RT_DEV bool bleaf_t(const SceneT<float> &sc, const BLeaf &lf, const RayT<float> 
         const float oa = axis == RTC_AXIS_YZ ? o.y : o.x, da = axis == RTC_AXIS_YZ ? d.y : d.x;
         const float ob = axis == RTC_AXIS_XY ? o.y : o.z, db = axis == RTC_AXIS_XY ? d.y : d.z;
         const float tt = (lf.d[0] - on) * __builtin_amdgcn_rcpf(dn);
-        if (tt < tmin || tt > tmax) return false;                      // a NaN t passes, like the reference (F20)
         const float pa = oa + tt * da, pb = ob + tt * db;
-        if (pa < lf.d[1] || pa > lf.d[3] || pb < lf.d[2] || pb > lf.d[4]) return false;
-        t = tt; return true;
+        t = tt;
+        // a ray cannot re-hit the plane it leaves; a NaN t passes the range test like in the reference (F20)
+        return !from_here & !(tt < tmin) & !(tt > tmax) & !(pa < lf.d[1]) & !(pa > lf.d[3]) & !(pb < lf.d[2]) & !(pb > lf.d[4]);
     }
-    if (type == RTC_PRIM_SPHERE) {
-        const V3<float> c = mk3<float>(lf.d[0], lf.d[1], lf.d[2]);
-        return from_here ? sphere_leave_t(c, r, tmin, tmax, t) : sphere_t<float>(c, lf.d[3], r, tmin, tmax, t);
-    }
-    if (type == RTC_PRIM_MSPHERE) {
-        const V3<float> c = mk3<float>(lf.d[0] + lf.d[3] * r.time, lf.d[1] + lf.d[4] * r.time, lf.d[2] + lf.d[5] * r.time);
-        return from_here ? sphere_leave_t(c, r, tmin, tmax, t) : sphere_t<float>(c, lf.d[6], r, tmin, tmax, t);
-    }
+    if (type == RTC_PRIM_SPHERE) return sphere_roots_f32(mk3<float>(lf.d[0], lf.d[1], lf.d[2]), lf.d[3], r, tmin, tmax, from_here, t);
+    if (type == RTC_PRIM_MSPHERE)
+        return sphere_roots_f32(mk3<float>(lf.d[0] + lf.d[3] * r.time, lf.d[1] + lf.d[4] * r.time, lf.d[2] + lf.d[5] * r.time), lf.d[6], r, tmin, tmax, from_here, t);
     return false;
 }
 // One loop, one step per trip: a lane either tests the two child boxes of an inner node or one leaf primitive, so lanes
@@ -264,46 +274,59 @@ RT_DEV void bvh_begin(BvhTrav &s, const RayT<float> &r, float tmax, int src_slot
     s.r = r; s.inv = mk3<float>(__builtin_amdgcn_rcpf(r.d.x), __builtin_amdgcn_rcpf(r.d.y), __builtin_amdgcn_rcpf(r.d.z));
     s.h.t = tmax; s.h.prim = -1; s.h.slot = -1; s.cur = 0; s.src_slot = src_slot;
 }
-template <typename Stack, typename MediumFn>
-RT_DEV void bvh_step(const SceneT<float> &sc, BvhTrav &s, float tmin, Stack &stack, MediumFn &&medium) {
-    if (s.cur >= 0) {
+template <typename Stack>
+RT_DEV void bvh_node_step(const SceneT<float> &sc, BvhTrav &s, float tmin, Stack &stack) {
 #if RT_EXP == 3
-        ++s.n_steps;
+    ++s.n_steps;
 #endif
-        const BvhNode nd = sc.nodes[s.cur];
-        float n0, n1;
-        const bool h0 = slab_f32(nd.lo0, nd.hi0, s.r.o, s.inv, tmin, s.h.t, n0), h1 = slab_f32(nd.lo1, nd.hi1, s.r.o, s.inv, tmin, s.h.t, n1);
-        if (h0 && h1) {
-            const bool first0 = n0 <= n1;
-            stack.push(first0 ? nd.child1 : nd.child0);
-            s.cur = first0 ? nd.child0 : nd.child1;
-        } else if (h0) s.cur = nd.child0;
-        else if (h1) s.cur = nd.child1;
-        else s.cur = stack.pop();
-    } else {
-#if RT_EXP == 4
-        ++s.n_steps;
-#endif
-        const int v = ~s.cur, slot = v >> 3, rem = v & 7;
-        const BLeaf lf = sc.bleaves[slot];
-        float t; bool hit;
-        int id = -1;
-        if ((lf.meta & 3u) == RTC_PRIM_MEDIUM) {
-            if (lf.meta & 0x80u) hit = medium.sphere_bounded(lf.d, s.r, s.h.t, t);
-            else { id = sc.leaf_prims[slot]; hit = medium(id, s.r, s.h.t, t); }
-        }
-        else hit = bleaf_t(sc, lf, s.r, tmin, s.h.t, slot == s.src_slot, t);
-        if (hit) {
-            if (id < 0) id = sc.leaf_prims[slot];
-            if (!(t == s.h.t && id < s.h.prim)) { s.h.t = t; s.h.prim = id; s.h.slot = slot; }
-        }
-        s.cur = rem ? ~(((slot + 1) << 3) | (rem - 1)) : stack.pop();
-    }
+    const BvhNode nd = sc.nodes[s.cur];
+    float n0, n1;
+    const bool h0 = slab_f32(nd.lo0, nd.hi0, s.r.o, s.inv, tmin, s.h.t, n0), h1 = slab_f32(nd.lo1, nd.hi1, s.r.o, s.inv, tmin, s.h.t, n1);
+    const bool both = h0 & h1, first0 = h0 & ((n0 <= n1) | !h1);   // the only hit child, or the nearer of two
+    if (both) stack.push(first0 ? nd.child1 : nd.child0);
+    s.cur = first0 ? nd.child0 : nd.child1;
+    if (!(h0 | h1)) s.cur = stack.pop();
 }
 template <typename Stack, typename MediumFn>
-RT_DEV HitS bvh_closest_hit(const SceneT<float> &sc, const RayT<float> &r, float tmin, float tmax, Stack &stack, MediumFn &&medium, int src_slot = -1) {
+RT_DEV void bvh_leaf_step(const SceneT<float> &sc, BvhTrav &s, float tmin, Stack &stack, MediumFn &&medium) {
+#if RT_EXP == 4
+    ++s.n_steps;
+#endif
+    const int v = ~s.cur, slot = v >> 3, rem = v & 7;
+    const BLeaf lf = sc.bleaves[slot];
+    float t; bool hit;
+    int id = -1;
+    if ((lf.meta & 3u) == RTC_PRIM_MEDIUM) {
+        if (lf.meta & 0x80u) hit = medium.sphere_bounded(lf.d, s.r, s.h.t, t);
+        else { id = sc.leaf_prims[slot]; hit = medium(id, s.r, s.h.t, t); }
+    }
+    else hit = bleaf_t(sc, lf, s.r, tmin, s.h.t, slot == s.src_slot, t);
+    if (hit) {
+        if (id < 0) id = sc.leaf_prims[slot];
+        if (!(t == s.h.t && id < s.h.prim)) { s.h.t = t; s.h.prim = id; s.h.slot = slot; }
+    }
+    s.cur = rem ? ~(((slot + 1) << 3) | (rem - 1)) : stack.pop();
+}
+template <typename Stack, typename MediumFn>
+RT_DEV void bvh_step(const SceneT<float> &sc, BvhTrav &s, float tmin, Stack &stack, MediumFn &&medium) {
+    if (s.cur >= 0) bvh_node_step(sc, s, tmin, stack);
+    else bvh_leaf_step(sc, s, tmin, stack, medium);
+}
+// Per trip: the lanes on an inner node take a node step; the lanes standing on a leaf take their leaf step only once
+// `leaf_batch` lanes of the wave wait on one (or no lane has a node left), because the leaf code runs for the whole wave
+// however few lanes need it.  leaf_batch <= 1 is the plain one-step-per-trip loop.
+template <typename Stack, typename MediumFn>
+RT_DEV HitS bvh_closest_hit(const SceneT<float> &sc, const RayT<float> &r, float tmin, float tmax, Stack &stack, MediumFn &&medium, int src_slot = -1,
+                            int leaf_batch = 1) {
     BvhTrav s; bvh_begin(s, r, tmax, src_slot);
-    while (s.cur != RTC_BVH_EMPTY) bvh_step(sc, s, tmin, stack, medium);
+    while (s.cur != RTC_BVH_EMPTY) {
+        const bool node = s.cur >= 0;
+        if (node) bvh_node_step(sc, s, tmin, stack);
+        const bool leaf = s.cur < 0 && s.cur != RTC_BVH_EMPTY && (leaf_batch > 1 || !node);
+        const int n_leaf = __builtin_popcountll(__builtin_amdgcn_ballot_w64(leaf));
+        const bool nodes_left = __builtin_amdgcn_ballot_w64(s.cur >= 0) != 0;
+        if (leaf && (n_leaf >= leaf_batch || !nodes_left)) bvh_leaf_step(sc, s, tmin, stack, medium);
+    }
 #if RT_EXP == 3 || RT_EXP == 4
     s.h.prim = (int)s.n_steps;                                   // probe builds return the step count in place of the primitive id
 #endif

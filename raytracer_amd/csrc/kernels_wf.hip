@@ -81,6 +81,16 @@ __global__ void __launch_bounds__(256) k_wf_init(CameraT<float> cam, RenderParam
 // and both were 35-40 % SLOWER: a refill puts a dependent slot-list -> ray-state load chain into the step loop and the
 // whole wave waits for it, while plain one-ray waves leave that latency to the other resident waves.
 // 6 waves per SIMD (80 VGPRs, 4 spilled in the medium path): +3 % over the uncapped 88; 8 waves (24 spilled) is slower
+// MEDIA (SceneT::media_kind) keeps the boundary-list loops of a general constant medium, and the Philox draws of any
+// medium, out of the kernels of scenes that have none.
+struct MediumSphereOnly : MediumSampler {
+    __device__ bool operator()(int, const RayT<float> &, float, float &) { return false; }
+};
+template <int MEDIA> struct WfMedium;
+template <> struct WfMedium<0> { using type = NoMedium32; };
+template <> struct WfMedium<1> { using type = MediumSphereOnly; };
+template <> struct WfMedium<2> { using type = MediumSampler; };
+template <int MEDIA>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) k_wf_extend(SceneT<float> sc, RenderParams P, WfBuffers B, int cur, unsigned n_list) {
     extern __shared__ int lds_stack[];                               // sc.bvh_depth entries per lane
     const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -93,9 +103,13 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) k
         const float4 o = B.ro[slot], d = B.rd[slot];
         const int4 m = B.meta[slot];                                 // sample, depth, src slot, pixel
         RayT<float> r; r.o = f3mk(o.x, o.y, o.z); r.d = f3mk(d.x, d.y, d.z); r.time = o.w;
-        MediumSampler medium{&sc, &r, 0.001f, (uint32_t)m.w, (uint32_t)m.x, (uint32_t)m.y, P.seed_lo, P.seed_hi, 0};
+        typename WfMedium<MEDIA>::type medium;
+        if constexpr (MEDIA != 0) {
+            medium.sc = &sc; medium.ray = &r; medium.tmin = 0.001f; medium.pixel = (uint32_t)m.w; medium.sample = (uint32_t)m.x; medium.bounce = (uint32_t)m.y;
+            medium.k0 = P.seed_lo; medium.k1 = P.seed_hi; medium.draws = 0;
+        }
         LdsStack stack(lds_stack + threadIdx.x, 256, sc.bvh_depth);
-        const HitS h = bvh_closest_hit(sc, r, 0.001f, Mth<float>::inf(), stack, medium, m.z);   // ray.c:56
+        const HitS h = bvh_closest_hit(sc, r, 0.001f, Mth<float>::inf(), stack, medium, m.z, P.leaf_batch);   // ray.c:56
         B.hit[slot] = make_float2(h.t, __int_as_float(h.slot));
         const uint32_t lm = h.slot >= 0 ? sc.bleaves[h.slot].meta : 0u;
         B.key[slot] = h.slot >= 0 ? (unsigned char)(((lm >> 4) & 7u) * 4u + ((lm >> 8) & 3u)) : (unsigned char)31;
@@ -247,7 +261,10 @@ hipError_t launch_wf_bounce(const SceneT<float> &sc, const CameraT<float> &cam, 
                             int cur, unsigned n_list, hipStream_t stream) {
     if (n_list == 0) return hipSuccess;
     const unsigned blocks = (n_list + 255) / 256;
-    hipLaunchKernelGGL(k_wf_extend, dim3(blocks), dim3(256), (size_t)sc.bvh_depth * 256 * sizeof(int), stream, sc, p, b, cur, n_list);
+    const size_t lds = (size_t)sc.bvh_depth * 256 * sizeof(int);
+    if (sc.media_kind == 0) hipLaunchKernelGGL(k_wf_extend<0>, dim3(blocks), dim3(256), lds, stream, sc, p, b, cur, n_list);
+    else if (sc.media_kind == 1) hipLaunchKernelGGL(k_wf_extend<1>, dim3(blocks), dim3(256), lds, stream, sc, p, b, cur, n_list);
+    else hipLaunchKernelGGL(k_wf_extend<2>, dim3(blocks), dim3(256), lds, stream, sc, p, b, cur, n_list);
     hipLaunchKernelGGL(k_wf_shade, dim3((n_list + kWfShadeBlock - 1) / kWfShadeBlock), dim3(kWfShadeBlock), 0, stream, sc, cam, p, b, cur, n_list);
     return hipGetLastError();
 }

@@ -81,6 +81,7 @@ template <typename R> hipError_t upload_tables(const FlatScene &fs, DeviceTables
     v.n_ref_steps = with_ref_steps ? (int)fs.ref_steps.size() : 0;
     v.bvh_depth = fs.bvh_depth < 1 ? 1 : (fs.bvh_depth > RTC_BVH_MAX_DEPTH ? RTC_BVH_MAX_DEPTH : fs.bvh_depth);
     v.n_media = fs.n_media;
+    v.media_kind = fs.n_media ? (fs.nodes.empty() ? 2 : fs.media_kind) : 0;
     for (int i = 0; i < 3; i++) v.background[i] = (R)fs.background[i];
     dt.ready = true;
     return hipSuccess;
@@ -367,6 +368,8 @@ int rtc_render_device(const rtc_scene *scene_c, const camera *cam, const rtc_set
     p.tiles_x = (st->width + 7) / 8; p.tiles_y = (st->height + 7) / 8; p.n_tiles = p.tiles_x * p.tiles_y;
     const CameraT<float> camf = camera_tables<float>(cam);
     p.use_time = camf.time0 != camf.time1;
+    p.leaf_batch = 8;
+    if (const char *e = std::getenv("RTC_LEAF_BATCH")) { const int v = std::atoi(e); if (v >= 1 && v <= 64) p.leaf_batch = v; }   // tuning knob
     HIP_TRY(hipMemsetAsync(s->ray_counter.p, 0, 4 * sizeof(unsigned long long), stream));
     HIP_TRY(hipEventRecord(ss.ev0, stream));
     const bool small = st->kernel == 2 || (st->kernel == 0 && s->small.n_leaves > 0);

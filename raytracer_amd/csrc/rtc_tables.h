@@ -76,6 +76,7 @@ template <typename R> struct SceneT {
     int bvh_depth;           // levels of the BVH = entries the traversal stack needs
     const RefStep *ref_steps; const double *ref_boxes; int n_ref_steps;   // FP64 check path; boxes = min xyz, max xyz
     int n_media;             // media among prims (stochastic hits)
+    int media_kind;          // BVH leaves: 0 no media, 1 sphere-bounded media only (BLeaf carries them), 2 general boundaries
     R background[3];
 };
 // ---- small-scene pack (FP32 production path for scenes of <= 64 rect/sphere leaves with solid textures) --------------

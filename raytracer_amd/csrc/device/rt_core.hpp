@@ -195,11 +195,13 @@ RT_DEV HitT<R> closest_hit_ref(const SceneT<R> &sc, const RayT<R> &r, R tmin, R 
 // broken explicitly -- the leaf with the highest visit-order index (primitive id) wins, which is what the reference's
 // left-then-right scan produces.
 // Slab test of one child box: entry distance in tn; boxes are padded outward at build time and the extra slack covers
-// the rounding of this test itself.  NaN (0 * inf on a degenerate axis) compares false and therefore keeps the node.
-RT_DEV bool slab_f32(const float *lo, const float *hi, V3<float> o, V3<float> inv, float tmin, float tmax, float &tn) {
-    const float x0 = (lo[0] - o.x) * inv.x, x1 = (hi[0] - o.x) * inv.x;
-    const float y0 = (lo[1] - o.y) * inv.y, y1 = (hi[1] - o.y) * inv.y;
-    const float z0 = (lo[2] - o.z) * inv.z, z1 = (hi[2] - o.z) * inv.z;
+// the rounding of this test itself.
+RT_DEV bool slab_f32(const float *lo, const float *hi, V3<float> noi, V3<float> inv, float tmin, float tmax, float &tn) {
+    // (lo - o) / d as one FMA per plane: lo * inv + noi with noi = -o * inv (bvh_begin).  Against (lo - o) * inv this
+    // moves the planes by up to |o| * 2^-24, the resolution of the FP32 ray origin itself; inv is finite (bvh_begin).
+    const float x0 = __builtin_fmaf(lo[0], inv.x, noi.x), x1 = __builtin_fmaf(hi[0], inv.x, noi.x);
+    const float y0 = __builtin_fmaf(lo[1], inv.y, noi.y), y1 = __builtin_fmaf(hi[1], inv.y, noi.y);
+    const float z0 = __builtin_fmaf(lo[2], inv.z, noi.z), z1 = __builtin_fmaf(hi[2], inv.z, noi.z);
     tn = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), tmin));
     const float tf = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fminf(fmaxf(z0, z1), tmax));
     return !(tn > tf * 1.0000001f + 1e-7f);
@@ -230,9 +232,13 @@ RT_DEV bool sphere_roots_f32(V3<float> c, float rad, const RayT<float> &r, float
     t = ok0 ? t0 : t1;
     return (from_here | (q >= 0.0f)) & (ok0 | ok1);
 }
+// KINDS: leaf types the scene's BVH holds (bit 0 rects, 1 spheres, 2 moving spheres; SceneT::leaf_kinds) -- a kernel for a
+// spheres-only scene carries no rect / transform code and fewer registers.
+enum { RTC_KIND_RECT = 1, RTC_KIND_SPHERE = 2, RTC_KIND_MSPHERE = 4, RTC_KIND_ALL = 7 };
+template <int KINDS = RTC_KIND_ALL>
 RT_DEV bool bleaf_t(const SceneT<float> &sc, const BLeaf &lf, const RayT<float> &r, float tmin, float tmax, bool from_here, float &t) {
     const uint32_t type = lf.meta & 3u;
-    if (type == RTC_PRIM_RECT) {
+    if ((KINDS & RTC_KIND_RECT) && type == RTC_PRIM_RECT) {
         V3<float> o = r.o, d = r.d;
         const uint32_t xf = lf.meta >> 12;
         if (xf) {
@@ -252,8 +258,9 @@ RT_DEV bool bleaf_t(const SceneT<float> &sc, const BLeaf &lf, const RayT<float> 
         // a ray cannot re-hit the plane it leaves; a NaN t passes the range test like in the reference (F20)
         return !from_here & !(tt < tmin) & !(tt > tmax) & !(pa < lf.d[1]) & !(pa > lf.d[3]) & !(pb < lf.d[2]) & !(pb > lf.d[4]);
     }
-    if (type == RTC_PRIM_SPHERE) return sphere_roots_f32(mk3<float>(lf.d[0], lf.d[1], lf.d[2]), lf.d[3], r, tmin, tmax, from_here, t);
-    if (type == RTC_PRIM_MSPHERE)
+    if ((KINDS & RTC_KIND_SPHERE) && (type == RTC_PRIM_SPHERE || KINDS == RTC_KIND_SPHERE))
+        return sphere_roots_f32(mk3<float>(lf.d[0], lf.d[1], lf.d[2]), lf.d[3], r, tmin, tmax, from_here, t);
+    if ((KINDS & RTC_KIND_MSPHERE) && type == RTC_PRIM_MSPHERE)
         return sphere_roots_f32(mk3<float>(lf.d[0] + lf.d[3] * r.time, lf.d[1] + lf.d[4] * r.time, lf.d[2] + lf.d[5] * r.time), lf.d[6], r, tmin, tmax, from_here, t);
     return false;
 }
@@ -265,13 +272,16 @@ RT_DEV bool bleaf_t(const SceneT<float> &sc, const BLeaf &lf, const RayT<float> 
 #define RT_EXP 0   // development probes; 0 in every shipped build
 #endif
 struct BvhTrav {
-    RayT<float> r; V3<float> inv; HitS h; int cur, src_slot;   // src_slot = leaf slot the ray starts on (-1: none)
+    RayT<float> r; V3<float> inv, noi; HitS h; int cur, src_slot;   // src_slot = leaf slot the ray starts on (-1: none)
 #if RT_EXP == 3 || RT_EXP == 4
     unsigned n_steps = 0;                                        // probe: node (3) or leaf (4) steps of this ray
 #endif
 };
 RT_DEV void bvh_begin(BvhTrav &s, const RayT<float> &r, float tmax, int src_slot) {
-    s.r = r; s.inv = mk3<float>(__builtin_amdgcn_rcpf(r.d.x), __builtin_amdgcn_rcpf(r.d.y), __builtin_amdgcn_rcpf(r.d.z));
+    // 1/d clamped to +-1e30: a zero component must not turn lo * inv - o * inv into inf - inf (slab_f32)
+    s.r = r; s.inv = mk3<float>(fminf(fmaxf(__builtin_amdgcn_rcpf(r.d.x), -1e30f), 1e30f), fminf(fmaxf(__builtin_amdgcn_rcpf(r.d.y), -1e30f), 1e30f),
+                                fminf(fmaxf(__builtin_amdgcn_rcpf(r.d.z), -1e30f), 1e30f));
+    s.noi = mk3<float>(-r.o.x * s.inv.x, -r.o.y * s.inv.y, -r.o.z * s.inv.z);
     s.h.t = tmax; s.h.prim = -1; s.h.slot = -1; s.cur = 0; s.src_slot = src_slot;
 }
 template <typename Stack>
@@ -281,30 +291,34 @@ RT_DEV void bvh_node_step(const SceneT<float> &sc, BvhTrav &s, float tmin, Stack
 #endif
     const BvhNode nd = sc.nodes[s.cur];
     float n0, n1;
-    const bool h0 = slab_f32(nd.lo0, nd.hi0, s.r.o, s.inv, tmin, s.h.t, n0), h1 = slab_f32(nd.lo1, nd.hi1, s.r.o, s.inv, tmin, s.h.t, n1);
+    const bool h0 = slab_f32(nd.lo0, nd.hi0, s.noi, s.inv, tmin, s.h.t, n0), h1 = slab_f32(nd.lo1, nd.hi1, s.noi, s.inv, tmin, s.h.t, n1);
     const bool both = h0 & h1, first0 = h0 & ((n0 <= n1) | !h1);   // the only hit child, or the nearer of two
     if (both) stack.push(first0 ? nd.child1 : nd.child0);
     s.cur = first0 ? nd.child0 : nd.child1;
     if (!(h0 | h1)) s.cur = stack.pop();
 }
-template <typename Stack, typename MediumFn>
+template <int KINDS = RTC_KIND_ALL, typename Stack, typename MediumFn>
 RT_DEV void bvh_leaf_step(const SceneT<float> &sc, BvhTrav &s, float tmin, Stack &stack, MediumFn &&medium) {
 #if RT_EXP == 4
     ++s.n_steps;
 #endif
     const int v = ~s.cur, slot = v >> 3, rem = v & 7;
-    const BLeaf lf = sc.bleaves[slot];
+    // both halves of the 32-B leaf are requested before anything looks at the type (otherwise the compiler fetches the
+    // type word first and the geometry in a second, dependent round trip)
+    const float4 *lp = reinterpret_cast<const float4 *>(sc.bleaves + slot);
+    float4 l0 = lp[0], l1 = lp[1];
+    asm volatile("" : "+v"(l0.x), "+v"(l1.w));
+    BLeaf lf; lf.d[0] = l0.x; lf.d[1] = l0.y; lf.d[2] = l0.z; lf.d[3] = l0.w; lf.d[4] = l1.x; lf.d[5] = l1.y; lf.d[6] = l1.z; lf.meta = __float_as_uint(l1.w);
     float t; bool hit;
-    int id = -1;
     if ((lf.meta & 3u) == RTC_PRIM_MEDIUM) {
         if (lf.meta & 0x80u) hit = medium.sphere_bounded(lf.d, s.r, s.h.t, t);
-        else { id = sc.leaf_prims[slot]; hit = medium(id, s.r, s.h.t, t); }
+        else hit = medium(sc.leaf_prims[slot], s.r, s.h.t, t);
     }
-    else hit = bleaf_t(sc, lf, s.r, tmin, s.h.t, slot == s.src_slot, t);
-    if (hit) {
-        if (id < 0) id = sc.leaf_prims[slot];
-        if (!(t == s.h.t && id < s.h.prim)) { s.h.t = t; s.h.prim = id; s.h.slot = slot; }
-    }
+    else hit = bleaf_t<KINDS>(sc, lf, s.r, tmin, s.h.t, slot == s.src_slot, t);
+    // an equal t is the only case that needs the primitive ids (the later leaf in the reference's visit order wins), so
+    // the slot -> id table is read there and once at the end, not on every accepted hit
+    if (hit && t == s.h.t && s.h.slot >= 0) hit = sc.leaf_prims[slot] >= sc.leaf_prims[s.h.slot];
+    if (hit) { s.h.t = t; s.h.slot = slot; }
     s.cur = rem ? ~(((slot + 1) << 3) | (rem - 1)) : stack.pop();
 }
 template <typename Stack, typename MediumFn>
@@ -315,7 +329,7 @@ RT_DEV void bvh_step(const SceneT<float> &sc, BvhTrav &s, float tmin, Stack &sta
 // Per trip: the lanes on an inner node take a node step; the lanes standing on a leaf take their leaf step only once
 // `leaf_batch` lanes of the wave wait on one (or no lane has a node left), because the leaf code runs for the whole wave
 // however few lanes need it.  leaf_batch <= 1 is the plain one-step-per-trip loop.
-template <typename Stack, typename MediumFn>
+template <int KINDS = RTC_KIND_ALL, typename Stack, typename MediumFn>
 RT_DEV HitS bvh_closest_hit(const SceneT<float> &sc, const RayT<float> &r, float tmin, float tmax, Stack &stack, MediumFn &&medium, int src_slot = -1,
                             int leaf_batch = 1) {
     BvhTrav s; bvh_begin(s, r, tmax, src_slot);
@@ -325,8 +339,9 @@ RT_DEV HitS bvh_closest_hit(const SceneT<float> &sc, const RayT<float> &r, float
         const bool leaf = s.cur < 0 && s.cur != RTC_BVH_EMPTY && (leaf_batch > 1 || !node);
         const int n_leaf = __builtin_popcountll(__builtin_amdgcn_ballot_w64(leaf));
         const bool nodes_left = __builtin_amdgcn_ballot_w64(s.cur >= 0) != 0;
-        if (leaf && (n_leaf >= leaf_batch || !nodes_left)) bvh_leaf_step(sc, s, tmin, stack, medium);
+        if (leaf && (n_leaf >= leaf_batch || !nodes_left)) bvh_leaf_step<KINDS>(sc, s, tmin, stack, medium);
     }
+    s.h.prim = s.h.slot >= 0 ? sc.leaf_prims[s.h.slot] : -1;
 #if RT_EXP == 3 || RT_EXP == 4
     s.h.prim = (int)s.n_steps;                                   // probe builds return the step count in place of the primitive id
 #endif

@@ -353,7 +353,7 @@ void to_world_point(const double M[9], const double b[3], const double p[3], dou
 // Traversal leaves of the FP32 production BVH (rtc_tables.h BLeaf), one per slot of leaf_prims.
 void build_bleaves(FlatScene &fs) {
     fs.bleaves.clear(); fs.bxforms.clear();
-    fs.media_kind = 0;
+    fs.media_kind = 0; fs.leaf_kinds = 0;
     BXform ident; for (int i = 0; i < 9; i++) ident.m[i] = (i % 4 == 0); ident.b[0] = ident.b[1] = ident.b[2] = 0;
     fs.bxforms.push_back(ident);
     std::map<int, int> xform_of_chain;
@@ -396,6 +396,7 @@ void build_bleaves(FlatScene &fs) {
             L.d[3] = (float)bp.d[3]; L.d[4] = (float)p.d[0];
             sphere_medium = 1u << 7;
         }
+        fs.leaf_kinds |= p.type == RTC_PRIM_RECT ? 1 : (p.type == RTC_PRIM_SPHERE ? 2 : (p.type == RTC_PRIM_MSPHERE ? 4 : 0));
         if (p.type == RTC_PRIM_MEDIUM) fs.media_kind = std::max(fs.media_kind, sphere_medium ? 1 : 2);
         const MaterialT<double> &pm = fs.materials[p.mat];
         const uint32_t tex_kind = pm.tex >= 0 ? (uint32_t)fs.textures[pm.tex].type : 0u;

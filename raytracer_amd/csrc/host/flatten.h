@@ -36,6 +36,7 @@ struct FlatScene {
     std::vector<int> wrap_depth;   // per prim: number of translate/rotate wrappers (for rtc_scene_dump_leaves)
     std::vector<int> flipped;      // per prim: parity of flip_face wrappers
     int n_media = 0;
+    int leaf_kinds = 0;             // leaf types in the production BVH: bit 0 rects, bit 1 spheres, bit 2 moving spheres
     int media_kind = 0;             // 0 none, 1 every medium is bounded by one sphere (carried in its BLeaf), 2 general boundaries
     double background[3] = {0, 0, 0};
     std::string error;

@@ -90,8 +90,8 @@ template <int MEDIA> struct WfMedium;
 template <> struct WfMedium<0> { using type = NoMedium32; };
 template <> struct WfMedium<1> { using type = MediumSphereOnly; };
 template <> struct WfMedium<2> { using type = MediumSampler; };
-template <int MEDIA>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) k_wf_extend(SceneT<float> sc, RenderParams P, WfBuffers B, int cur, unsigned n_list) {
+template <int MEDIA, int KINDS>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KINDS == RTC_KIND_SPHERE ? 8 : 6))) k_wf_extend(SceneT<float> sc, RenderParams P, WfBuffers B, int cur, unsigned n_list) {
     extern __shared__ int lds_stack[];                               // sc.bvh_depth entries per lane
     const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
     const int slot = i < n_list ? B.active[cur][i] : -1;
@@ -109,7 +109,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) k
             medium.k0 = P.seed_lo; medium.k1 = P.seed_hi; medium.draws = 0;
         }
         LdsStack stack(lds_stack + threadIdx.x, 256, sc.bvh_depth);
-        const HitS h = bvh_closest_hit(sc, r, 0.001f, Mth<float>::inf(), stack, medium, m.z, P.leaf_batch);   // ray.c:56
+        const HitS h = bvh_closest_hit<KINDS>(sc, r, 0.001f, Mth<float>::inf(), stack, medium, m.z, P.leaf_batch);   // ray.c:56
         B.hit[slot] = make_float2(h.t, __int_as_float(h.slot));
         const uint32_t lm = h.slot >= 0 ? sc.bleaves[h.slot].meta : 0u;
         B.key[slot] = h.slot >= 0 ? (unsigned char)(((lm >> 4) & 7u) * 4u + ((lm >> 8) & 3u)) : (unsigned char)31;
@@ -262,9 +262,10 @@ hipError_t launch_wf_bounce(const SceneT<float> &sc, const CameraT<float> &cam, 
     if (n_list == 0) return hipSuccess;
     const unsigned blocks = (n_list + 255) / 256;
     const size_t lds = (size_t)sc.bvh_depth * 256 * sizeof(int);
-    if (sc.media_kind == 0) hipLaunchKernelGGL(k_wf_extend<0>, dim3(blocks), dim3(256), lds, stream, sc, p, b, cur, n_list);
-    else if (sc.media_kind == 1) hipLaunchKernelGGL(k_wf_extend<1>, dim3(blocks), dim3(256), lds, stream, sc, p, b, cur, n_list);
-    else hipLaunchKernelGGL(k_wf_extend<2>, dim3(blocks), dim3(256), lds, stream, sc, p, b, cur, n_list);
+    if (sc.media_kind == 0 && sc.leaf_kinds == RTC_KIND_SPHERE) hipLaunchKernelGGL((k_wf_extend<0, RTC_KIND_SPHERE>), dim3(blocks), dim3(256), lds, stream, sc, p, b, cur, n_list);
+    else if (sc.media_kind == 0) hipLaunchKernelGGL((k_wf_extend<0, RTC_KIND_ALL>), dim3(blocks), dim3(256), lds, stream, sc, p, b, cur, n_list);
+    else if (sc.media_kind == 1) hipLaunchKernelGGL((k_wf_extend<1, RTC_KIND_ALL>), dim3(blocks), dim3(256), lds, stream, sc, p, b, cur, n_list);
+    else hipLaunchKernelGGL((k_wf_extend<2, RTC_KIND_ALL>), dim3(blocks), dim3(256), lds, stream, sc, p, b, cur, n_list);
     hipLaunchKernelGGL(k_wf_shade, dim3((n_list + kWfShadeBlock - 1) / kWfShadeBlock), dim3(kWfShadeBlock), 0, stream, sc, cam, p, b, cur, n_list);
     return hipGetLastError();
 }

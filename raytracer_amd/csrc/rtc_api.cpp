@@ -81,6 +81,7 @@ template <typename R> hipError_t upload_tables(const FlatScene &fs, DeviceTables
     v.n_ref_steps = with_ref_steps ? (int)fs.ref_steps.size() : 0;
     v.bvh_depth = fs.bvh_depth < 1 ? 1 : (fs.bvh_depth > RTC_BVH_MAX_DEPTH ? RTC_BVH_MAX_DEPTH : fs.bvh_depth);
     v.n_media = fs.n_media;
+    v.leaf_kinds = fs.leaf_kinds;
     v.media_kind = fs.n_media ? (fs.nodes.empty() ? 2 : fs.media_kind) : 0;
     for (int i = 0; i < 3; i++) v.background[i] = (R)fs.background[i];
     dt.ready = true;

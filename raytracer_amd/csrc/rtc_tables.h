@@ -76,6 +76,7 @@ template <typename R> struct SceneT {
     int bvh_depth;           // levels of the BVH = entries the traversal stack needs
     const RefStep *ref_steps; const double *ref_boxes; int n_ref_steps;   // FP64 check path; boxes = min xyz, max xyz
     int n_media;             // media among prims (stochastic hits)
+    int leaf_kinds;          // BVH leaves: bit 0 rects, bit 1 spheres, bit 2 moving spheres (RTC_KIND_*, rt_core.hpp)
     int media_kind;          // BVH leaves: 0 no media, 1 sphere-bounded media only (BLeaf carries them), 2 general boundaries
     R background[3];
 };

@@ -266,8 +266,7 @@ RT_DEV bool bleaf_t(const SceneT<float> &sc, const BLeaf &lf, const RayT<float> 
 }
 // One loop, one step per trip: a lane either tests the two child boxes of an inner node or one leaf primitive, so lanes
 // of a wave that are in different phases of their traversal never wait for each other's inner loops.  The nearer child
-// is entered first; the farther one waits on the stack.  The traversal is a resumable state machine (bvh_begin /
-// bvh_step) so that a persistent wave can hand a finished lane its next ray while the other lanes keep walking.
+// is entered first; the farther one waits on the stack.
 #ifndef RT_EXP
 #define RT_EXP 0   // development probes; 0 in every shipped build
 #endif
@@ -285,11 +284,10 @@ RT_DEV void bvh_begin(BvhTrav &s, const RayT<float> &r, float tmax, int src_slot
     s.h.t = tmax; s.h.prim = -1; s.h.slot = -1; s.cur = 0; s.src_slot = src_slot;
 }
 template <typename Stack>
-RT_DEV void bvh_node_step(const SceneT<float> &sc, BvhTrav &s, float tmin, Stack &stack) {
+RT_DEV void bvh_node_step(const BvhNode &nd, BvhTrav &s, float tmin, Stack &stack) {
 #if RT_EXP == 3
     ++s.n_steps;
 #endif
-    const BvhNode nd = sc.nodes[s.cur];
     float n0, n1;
     const bool h0 = slab_f32(nd.lo0, nd.hi0, s.noi, s.inv, tmin, s.h.t, n0), h1 = slab_f32(nd.lo1, nd.hi1, s.noi, s.inv, tmin, s.h.t, n1);
     const bool both = h0 & h1, first0 = h0 & ((n0 <= n1) | !h1);   // the only hit child, or the nearer of two
@@ -298,17 +296,11 @@ RT_DEV void bvh_node_step(const SceneT<float> &sc, BvhTrav &s, float tmin, Stack
     if (!(h0 | h1)) s.cur = stack.pop();
 }
 template <int KINDS = RTC_KIND_ALL, typename Stack, typename MediumFn>
-RT_DEV void bvh_leaf_step(const SceneT<float> &sc, BvhTrav &s, float tmin, Stack &stack, MediumFn &&medium) {
+RT_DEV void bvh_leaf_step(const SceneT<float> &sc, const BLeaf &lf, BvhTrav &s, float tmin, Stack &stack, MediumFn &&medium) {
 #if RT_EXP == 4
     ++s.n_steps;
 #endif
     const int v = ~s.cur, slot = v >> 3, rem = v & 7;
-    // both halves of the 32-B leaf are requested before anything looks at the type (otherwise the compiler fetches the
-    // type word first and the geometry in a second, dependent round trip)
-    const float4 *lp = reinterpret_cast<const float4 *>(sc.bleaves + slot);
-    float4 l0 = lp[0], l1 = lp[1];
-    asm volatile("" : "+v"(l0.x), "+v"(l1.w));
-    BLeaf lf; lf.d[0] = l0.x; lf.d[1] = l0.y; lf.d[2] = l0.z; lf.d[3] = l0.w; lf.d[4] = l1.x; lf.d[5] = l1.y; lf.d[6] = l1.z; lf.meta = __float_as_uint(l1.w);
     float t; bool hit;
     if ((lf.meta & 3u) == RTC_PRIM_MEDIUM) {
         if (lf.meta & 0x80u) hit = medium.sphere_bounded(lf.d, s.r, s.h.t, t);
@@ -321,25 +313,29 @@ RT_DEV void bvh_leaf_step(const SceneT<float> &sc, BvhTrav &s, float tmin, Stack
     if (hit) { s.h.t = t; s.h.slot = slot; }
     s.cur = rem ? ~(((slot + 1) << 3) | (rem - 1)) : stack.pop();
 }
-template <typename Stack, typename MediumFn>
-RT_DEV void bvh_step(const SceneT<float> &sc, BvhTrav &s, float tmin, Stack &stack, MediumFn &&medium) {
-    if (s.cur >= 0) bvh_node_step(sc, s, tmin, stack);
-    else bvh_leaf_step(sc, s, tmin, stack, medium);
-}
-// Per trip: the lanes on an inner node take a node step; the lanes standing on a leaf take their leaf step only once
-// `leaf_batch` lanes of the wave wait on one (or no lane has a node left), because the leaf code runs for the whole wave
-// however few lanes need it.  leaf_batch <= 1 is the plain one-step-per-trip loop.
+// One trip = one memory round trip for the whole wave: every lane requests 64 bytes from what it stands on at the top of
+// the trip -- its node, or its 32-byte leaf and whatever follows it (the leaf table ends in one spare entry) -- and only
+// then do the two arms run.  Written as `if (node) { load; test } else { load; test }` the compiler waits for each arm's
+// own load inside the arm (and moves shared loads into the arms if they are not pinned), so a wave with lanes in both
+// phases pays two dependent round trips per trip.
 template <int KINDS = RTC_KIND_ALL, typename Stack, typename MediumFn>
-RT_DEV HitS bvh_closest_hit(const SceneT<float> &sc, const RayT<float> &r, float tmin, float tmax, Stack &stack, MediumFn &&medium, int src_slot = -1,
-                            int leaf_batch = 1) {
+RT_DEV HitS bvh_closest_hit(const SceneT<float> &sc, const RayT<float> &r, float tmin, float tmax, Stack &stack, MediumFn &&medium, int src_slot = -1) {
     BvhTrav s; bvh_begin(s, r, tmax, src_slot);
     while (s.cur != RTC_BVH_EMPTY) {
         const bool node = s.cur >= 0;
-        if (node) bvh_node_step(sc, s, tmin, stack);
-        const bool leaf = s.cur < 0 && s.cur != RTC_BVH_EMPTY && (leaf_batch > 1 || !node);
-        const int n_leaf = __builtin_popcountll(__builtin_amdgcn_ballot_w64(leaf));
-        const bool nodes_left = __builtin_amdgcn_ballot_w64(s.cur >= 0) != 0;
-        if (leaf && (n_leaf >= leaf_batch || !nodes_left)) bvh_leaf_step<KINDS>(sc, s, tmin, stack, medium);
+        const float4 *ptr = node ? reinterpret_cast<const float4 *>(sc.nodes + s.cur) : reinterpret_cast<const float4 *>(sc.bleaves + ((~s.cur) >> 3));
+        float4 q0 = ptr[0], q1 = ptr[1], q2 = ptr[2], q3 = ptr[3];
+        asm volatile("" : "+v"(q0.x), "+v"(q1.x), "+v"(q2.x), "+v"(q3.x));   // pins the four loads here, ahead of both arms
+        if (node) {
+            BvhNode nd;
+            nd.lo0[0] = q0.x; nd.lo0[1] = q0.y; nd.lo0[2] = q0.z; nd.child0 = __float_as_int(q0.w); nd.hi0[0] = q1.x; nd.hi0[1] = q1.y; nd.hi0[2] = q1.z;
+            nd.lo1[0] = q2.x; nd.lo1[1] = q2.y; nd.lo1[2] = q2.z; nd.child1 = __float_as_int(q2.w); nd.hi1[0] = q3.x; nd.hi1[1] = q3.y; nd.hi1[2] = q3.z;
+            bvh_node_step(nd, s, tmin, stack);
+        } else {
+            BLeaf lf;
+            lf.d[0] = q0.x; lf.d[1] = q0.y; lf.d[2] = q0.z; lf.d[3] = q0.w; lf.d[4] = q1.x; lf.d[5] = q1.y; lf.d[6] = q1.z; lf.meta = __float_as_uint(q1.w);
+            bvh_leaf_step<KINDS>(sc, lf, s, tmin, stack, medium);
+        }
     }
     s.h.prim = s.h.slot >= 0 ? sc.leaf_prims[s.h.slot] : -1;
 #if RT_EXP == 3 || RT_EXP == 4

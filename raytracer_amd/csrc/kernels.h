@@ -14,7 +14,6 @@ struct RenderParams {
     float light_weight;
     int tiles_x, tiles_y, n_tiles;   // 8x8-pixel tiles, one wave each
     int use_time;                    // camera shutter open (time0 != time1)
-    int leaf_batch;                  // BVH traversal: lanes of a wave that must wait on a leaf before the leaf code runs (rt_core.hpp)
 };
 
 hipError_t launch_first_hit_f64(const SceneT<double> &sc, const double *rays7, size_t n, double tmin, double tmax,

@@ -109,7 +109,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KINDS 
             medium.k0 = P.seed_lo; medium.k1 = P.seed_hi; medium.draws = 0;
         }
         LdsStack stack(lds_stack + threadIdx.x, 256, sc.bvh_depth);
-        const HitS h = bvh_closest_hit<KINDS>(sc, r, 0.001f, Mth<float>::inf(), stack, medium, m.z, P.leaf_batch);   // ray.c:56
+        const HitS h = bvh_closest_hit<KINDS>(sc, r, 0.001f, Mth<float>::inf(), stack, medium, m.z);   // ray.c:56
         B.hit[slot] = make_float2(h.t, __int_as_float(h.slot));
         const uint32_t lm = h.slot >= 0 ? sc.bleaves[h.slot].meta : 0u;
         B.key[slot] = h.slot >= 0 ? (unsigned char)(((lm >> 4) & 7u) * 4u + ((lm >> 8) & 3u)) : (unsigned char)31;

@@ -64,7 +64,11 @@ template <typename R> hipError_t upload_tables(const FlatScene &fs, DeviceTables
     UP(prims, prims); UP(bprims, bprims); UP(ops, ops); UP(chains, fs.chains); UP(materials, mats); UP(textures, texs); UP(lights, lights);
     UP(perlin_vec, pvec); UP(perlin_perm, fs.perlin_perm); UP(images, fs.images); UP(image_data, fs.image_data); UP(nodes, fs.nodes); UP(leaf_prims, fs.leaf_prims);
     if (with_ref_steps) { UP(ref_steps, fs.ref_steps); UP(ref_boxes, fs.ref_boxes); }
-    else { UP(bleaves, fs.bleaves); UP(bxforms, fs.bxforms); }
+    else {
+        // one zeroed leaf past the end: the traversal fetches 64 bytes from whatever a lane stands on (bvh_closest_hit)
+        std::vector<BLeaf> padded(fs.bleaves); BLeaf z; std::memset(&z, 0, sizeof z); padded.push_back(z);
+        UP(bleaves, padded); UP(bxforms, fs.bxforms);
+    }
 #undef UP
     SceneT<R> &v = dt.view;
     v.prims = (const PrimT<R> *)dt.prims.p; v.n_prims = (int)fs.prims.size();
@@ -369,8 +373,6 @@ int rtc_render_device(const rtc_scene *scene_c, const camera *cam, const rtc_set
     p.tiles_x = (st->width + 7) / 8; p.tiles_y = (st->height + 7) / 8; p.n_tiles = p.tiles_x * p.tiles_y;
     const CameraT<float> camf = camera_tables<float>(cam);
     p.use_time = camf.time0 != camf.time1;
-    p.leaf_batch = 8;
-    if (const char *e = std::getenv("RTC_LEAF_BATCH")) { const int v = std::atoi(e); if (v >= 1 && v <= 64) p.leaf_batch = v; }   // tuning knob
     HIP_TRY(hipMemsetAsync(s->ray_counter.p, 0, 4 * sizeof(unsigned long long), stream));
     HIP_TRY(hipEventRecord(ss.ev0, stream));
     const bool small = st->kernel == 2 || (st->kernel == 0 && s->small.n_leaves > 0);

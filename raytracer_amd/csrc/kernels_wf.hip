@@ -90,8 +90,13 @@ template <int MEDIA> struct WfMedium;
 template <> struct WfMedium<0> { using type = NoMedium32; };
 template <> struct WfMedium<1> { using type = MediumSphereOnly; };
 template <> struct WfMedium<2> { using type = MediumSampler; };
+constexpr int kWfStripes = 64;   // cache lines each statistic is striped over
+#ifndef RT_WF_EXTEND_BLOCK
+#define RT_WF_EXTEND_BLOCK 64
+#endif
+constexpr int kWfExtendBlock = RT_WF_EXTEND_BLOCK;
 template <int MEDIA, int KINDS>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KINDS == RTC_KIND_SPHERE ? 8 : 6))) k_wf_extend(SceneT<float> sc, RenderParams P, WfBuffers B, int cur, unsigned n_list) {
+__global__ void __launch_bounds__(kWfExtendBlock) __attribute__((amdgpu_waves_per_eu(KINDS == RTC_KIND_SPHERE ? 8 : 6))) k_wf_extend(SceneT<float> sc, RenderParams P, WfBuffers B, int cur, unsigned n_list) {
     extern __shared__ int lds_stack[];                               // sc.bvh_depth entries per lane
     const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
     const int slot = i < n_list ? B.active[cur][i] : -1;
@@ -108,7 +113,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KINDS 
             medium.sc = &sc; medium.ray = &r; medium.tmin = 0.001f; medium.pixel = (uint32_t)m.w; medium.sample = (uint32_t)m.x; medium.bounce = (uint32_t)m.y;
             medium.k0 = P.seed_lo; medium.k1 = P.seed_hi; medium.draws = 0;
         }
-        LdsStack stack(lds_stack + threadIdx.x, 256, sc.bvh_depth);
+        LdsStack stack(lds_stack + threadIdx.x, kWfExtendBlock, sc.bvh_depth);
         const HitS h = bvh_closest_hit<KINDS>(sc, r, 0.001f, Mth<float>::inf(), stack, medium, m.z);   // ray.c:56
         B.hit[slot] = make_float2(h.t, __int_as_float(h.slot));
         const uint32_t lm = h.slot >= 0 ? sc.bleaves[h.slot].meta : 0u;
@@ -117,7 +122,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KINDS 
         probe_n = (unsigned)h.prim;
 #endif
     }
-    // statistics: two fire-and-forget atomics per block, striped over 8 cache lines each
+    // statistics: two fire-and-forget atomics per block, striped over kWfStripes cache lines each
     const unsigned long long mask = __builtin_amdgcn_ballot_w64(live);
     const int rays = __syncthreads_count(live);
 #if RT_EXP == 3 || RT_EXP == 4   // probe: total node / leaf steps instead of the wave count
@@ -131,8 +136,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KINDS 
     const int waves = __syncthreads_count(mask != 0 && (threadIdx.x & 63) == 0);
 #endif
     if (threadIdx.x == 0 && rays) {
-        atomicAdd(B.stats + 8 * (1 + (blockIdx.x & 7)), (unsigned long long)rays);
-        atomicAdd(B.stats + 8 * (9 + (blockIdx.x & 7)), (unsigned long long)waves);
+        atomicAdd(B.stats + 8 * (1 + (blockIdx.x & (kWfStripes - 1))), (unsigned long long)rays);
+        atomicAdd(B.stats + 8 * (1 + kWfStripes + (blockIdx.x & (kWfStripes - 1))), (unsigned long long)waves);
     }
 }
 
@@ -232,7 +237,7 @@ __global__ void __launch_bounds__(256) k_wf_finish(RenderParams P, WfBuffers B, 
     const int q = blockIdx.x * blockDim.x + threadIdx.x;            // slot of layer 0
     if (q == 0) {                                                    // fold the striped statistics
         unsigned long long rays = 0, waves = 0;
-        for (int k = 0; k < 8; ++k) { rays += stats[8 * (1 + k)]; waves += stats[8 * (9 + k)]; }
+        for (int k = 0; k < kWfStripes; ++k) { rays += stats[8 * (1 + k)]; waves += stats[8 * (1 + kWfStripes + k)]; }
         stats[0] += rays; stats[1] += waves;
     }
     if (q >= B.slots_per_layer) return;
@@ -248,11 +253,11 @@ __global__ void __launch_bounds__(256) k_wf_finish(RenderParams P, WfBuffers B, 
 }  // namespace
 
 size_t wf_bytes_per_slot() { return 4 * sizeof(float4) + sizeof(int4) + sizeof(float2) + 2 * sizeof(int) + 1; }
-size_t wf_stats_bytes() { return 17 * 8 * sizeof(unsigned long long); }   // 17 cache lines of 64 bytes
+size_t wf_stats_bytes() { return (1 + 2 * kWfStripes) * 8 * sizeof(unsigned long long); }   // cache lines of 64 bytes
 
 hipError_t launch_wf_init(const CameraT<float> &cam, const RenderParams &p, const WfBuffers &b, hipStream_t stream) {
     hipError_t e = hipMemsetAsync(b.counters, 0, 16 * sizeof(unsigned), stream);
-    if (e == hipSuccess) e = hipMemsetAsync(b.stats + 8, 0, 16 * 8 * sizeof(unsigned long long), stream);
+    if (e == hipSuccess) e = hipMemsetAsync(b.stats + 8, 0, 2 * kWfStripes * 8 * sizeof(unsigned long long), stream);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_wf_init, dim3((unsigned)((b.n_slots + 255) / 256)), dim3(256), 0, stream, cam, p, b);
     return hipGetLastError();
@@ -260,12 +265,12 @@ hipError_t launch_wf_init(const CameraT<float> &cam, const RenderParams &p, cons
 hipError_t launch_wf_bounce(const SceneT<float> &sc, const CameraT<float> &cam, const RenderParams &p, const WfBuffers &b,
                             int cur, unsigned n_list, hipStream_t stream) {
     if (n_list == 0) return hipSuccess;
-    const unsigned blocks = (n_list + 255) / 256;
-    const size_t lds = (size_t)sc.bvh_depth * 256 * sizeof(int);
-    if (sc.media_kind == 0 && sc.leaf_kinds == RTC_KIND_SPHERE) hipLaunchKernelGGL((k_wf_extend<0, RTC_KIND_SPHERE>), dim3(blocks), dim3(256), lds, stream, sc, p, b, cur, n_list);
-    else if (sc.media_kind == 0) hipLaunchKernelGGL((k_wf_extend<0, RTC_KIND_ALL>), dim3(blocks), dim3(256), lds, stream, sc, p, b, cur, n_list);
-    else if (sc.media_kind == 1) hipLaunchKernelGGL((k_wf_extend<1, RTC_KIND_ALL>), dim3(blocks), dim3(256), lds, stream, sc, p, b, cur, n_list);
-    else hipLaunchKernelGGL((k_wf_extend<2, RTC_KIND_ALL>), dim3(blocks), dim3(256), lds, stream, sc, p, b, cur, n_list);
+    const unsigned blocks = (n_list + kWfExtendBlock - 1) / kWfExtendBlock;
+    const size_t lds = (size_t)sc.bvh_depth * kWfExtendBlock * sizeof(int);
+    if (sc.media_kind == 0 && sc.leaf_kinds == RTC_KIND_SPHERE) hipLaunchKernelGGL((k_wf_extend<0, RTC_KIND_SPHERE>), dim3(blocks), dim3(kWfExtendBlock), lds, stream, sc, p, b, cur, n_list);
+    else if (sc.media_kind == 0) hipLaunchKernelGGL((k_wf_extend<0, RTC_KIND_ALL>), dim3(blocks), dim3(kWfExtendBlock), lds, stream, sc, p, b, cur, n_list);
+    else if (sc.media_kind == 1) hipLaunchKernelGGL((k_wf_extend<1, RTC_KIND_ALL>), dim3(blocks), dim3(kWfExtendBlock), lds, stream, sc, p, b, cur, n_list);
+    else hipLaunchKernelGGL((k_wf_extend<2, RTC_KIND_ALL>), dim3(blocks), dim3(kWfExtendBlock), lds, stream, sc, p, b, cur, n_list);
     hipLaunchKernelGGL(k_wf_shade, dim3((n_list + kWfShadeBlock - 1) / kWfShadeBlock), dim3(kWfShadeBlock), 0, stream, sc, cam, p, b, cur, n_list);
     return hipGetLastError();
 }

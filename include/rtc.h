@@ -80,9 +80,9 @@ int  rtc_scene_dump_leaves(const rtc_scene *scene, double *out16, int cap);
 int  rtc_scene_bvh_info(const rtc_scene *scene, long long *out4);
 /* The production BVH itself, for structural checks on a machine without a GPU: nodes16 = per inner node 16 words (float
  * lo0[3], int child0, float hi0[3], int count0, the same for child 1; child < 0 encodes a leaf run ~((first << 3) | (count-1))),
- * leaves8 = per leaf slot 8 words (7 floats of world-space geometry + meta), prim_of_slot = primitive id per leaf slot.
+ * leaves16 = per leaf slot 16 words (15 floats of world-space geometry + meta), prim_of_slot = primitive id per leaf slot.
  * Any pointer may be NULL; the caps are in entries.  Returns the number of leaf slots. */
-int  rtc_scene_dump_bvh(const rtc_scene *scene, void *nodes16, int node_cap, void *leaves8, int *prim_of_slot, int leaf_cap);
+int  rtc_scene_dump_bvh(const rtc_scene *scene, void *nodes16, int node_cap, void *leaves16, int *prim_of_slot, int leaf_cap);
 
 /* FP64, no-FMA closest hit for n host rays (7 doubles each: orig, dir, time): bit-exact replacement of
  * hittable_list_hit(world, r, tmin, tmax, &rec) (hittable_list.c:125-143).  prim_id[i] = -1 on miss.

@@ -47,7 +47,7 @@ class RtcStats(C.Structure):
 
 
 SCENES = dict(simple=0, cornell=1, final=2, book1=3, cornell02=4, cornell_smoke=5, two_spheres=6, two_perlin=7,
-              simple_light=8, book2_random=9, million=10, earth=11, final_earth=12)
+              simple_light=8, book2_random=9, million=10, earth=11, final_earth=12, box_field=13)
 EARTHMAP = os.path.join(os.path.dirname(_HERE), "tests", "golden", "earthmap_512.ppm")
 
 _P = C.c_void_p
@@ -212,10 +212,10 @@ class Scene:
         return dict(nodes=out[0], leaf_slots=out[1], depth=out[2], bytes=out[3])
 
     def dump_bvh(self):
-        """(nodes uint32[n, 16], leaves uint32[m, 8], prim_of_slot int32[m]); view the float fields with .view(np.float32)."""
+        """(nodes uint32[n, 16], leaves uint32[m, 16], prim_of_slot int32[m]); view the float fields with .view(np.float32)."""
         info = self.bvh_info()
         nodes = np.zeros((max(info["nodes"], 1), 16), dtype=np.uint32)
-        leaves = np.zeros((max(info["leaf_slots"], 1), 8), dtype=np.uint32)
+        leaves = np.zeros((max(info["leaf_slots"], 1), 16), dtype=np.uint32)
         prims = np.zeros(max(info["leaf_slots"], 1), dtype=np.int32)
         n = lib().rtc_scene_dump_bvh(self.handle, nodes.ctypes.data, info["nodes"], leaves.ctypes.data, prims.ctypes.data, info["leaf_slots"])
         if n < 0:

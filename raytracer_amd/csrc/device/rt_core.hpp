@@ -236,27 +236,16 @@ RT_DEV bool sphere_roots_f32(V3<float> c, float rad, const RayT<float> &r, float
 // spheres-only scene carries no rect / transform code and fewer registers.
 enum { RTC_KIND_RECT = 1, RTC_KIND_SPHERE = 2, RTC_KIND_MSPHERE = 4, RTC_KIND_ALL = 7 };
 template <int KINDS = RTC_KIND_ALL>
-RT_DEV bool bleaf_t(const SceneT<float> &sc, const BLeaf &lf, const RayT<float> &r, float tmin, float tmax, bool from_here, float &t) {
+RT_DEV bool bleaf_t(const BLeaf &lf, const RayT<float> &r, float tmin, float tmax, bool from_here, float &t) {
     const uint32_t type = lf.meta & 3u;
     if ((KINDS & RTC_KIND_RECT) && type == RTC_PRIM_RECT) {
-        V3<float> o = r.o, d = r.d;
-        const uint32_t xf = lf.meta >> 12;
-        if (xf) {
-            const BXform x = sc.bxforms[xf];
-            o = mk3<float>(x.m[0] * r.o.x + x.m[1] * r.o.y + x.m[2] * r.o.z + x.b[0], x.m[3] * r.o.x + x.m[4] * r.o.y + x.m[5] * r.o.z + x.b[1],
-                           x.m[6] * r.o.x + x.m[7] * r.o.y + x.m[8] * r.o.z + x.b[2]);
-            d = mk3<float>(x.m[0] * r.d.x + x.m[1] * r.d.y + x.m[2] * r.d.z, x.m[3] * r.d.x + x.m[4] * r.d.y + x.m[5] * r.d.z,
-                           x.m[6] * r.d.x + x.m[7] * r.d.y + x.m[8] * r.d.z);
-        }
-        const uint32_t axis = (lf.meta >> 2) & 3u;
-        const float on = axis == RTC_AXIS_XY ? o.z : (axis == RTC_AXIS_XZ ? o.y : o.x), dn = axis == RTC_AXIS_XY ? d.z : (axis == RTC_AXIS_XZ ? d.y : d.x);
-        const float oa = axis == RTC_AXIS_YZ ? o.y : o.x, da = axis == RTC_AXIS_YZ ? d.y : d.x;
-        const float ob = axis == RTC_AXIS_XY ? o.y : o.z, db = axis == RTC_AXIS_XY ? d.y : d.z;
-        const float tt = (lf.d[0] - on) * __builtin_amdgcn_rcpf(dn);
-        const float pa = oa + tt * da, pb = ob + tt * db;
+        const V3<float> N = mk3<float>(lf.d[0], lf.d[1], lf.d[2]), U = mk3<float>(lf.d[4], lf.d[5], lf.d[6]), V = mk3<float>(lf.d[8], lf.d[9], lf.d[10]);
+        const float tt = (lf.d[3] - dot(N, r.o)) * __builtin_amdgcn_rcpf(dot(N, r.d));
+        const V3<float> p = r.o + r.d * tt;
+        const float pa = dot(U, p), pb = dot(V, p);
         t = tt;
         // a ray cannot re-hit the plane it leaves; a NaN t passes the range test like in the reference (F20)
-        return !from_here & !(tt < tmin) & !(tt > tmax) & !(pa < lf.d[1]) & !(pa > lf.d[3]) & !(pb < lf.d[2]) & !(pb > lf.d[4]);
+        return !from_here & !(tt < tmin) & !(tt > tmax) & !(pa < lf.d[7]) & !(pa > lf.d[12]) & !(pb < lf.d[11]) & !(pb > lf.d[13]);
     }
     if ((KINDS & RTC_KIND_SPHERE) && (type == RTC_PRIM_SPHERE || KINDS == RTC_KIND_SPHERE))
         return sphere_roots_f32(mk3<float>(lf.d[0], lf.d[1], lf.d[2]), lf.d[3], r, tmin, tmax, from_here, t);
@@ -306,18 +295,18 @@ RT_DEV void bvh_leaf_step(const SceneT<float> &sc, const BLeaf &lf, BvhTrav &s, 
         if (lf.meta & 0x80u) hit = medium.sphere_bounded(lf.d, s.r, s.h.t, t);
         else hit = medium(sc.leaf_prims[slot], s.r, s.h.t, t);
     }
-    else hit = bleaf_t<KINDS>(sc, lf, s.r, tmin, s.h.t, slot == s.src_slot, t);
+    else hit = bleaf_t<KINDS>(lf, s.r, tmin, s.h.t, slot == s.src_slot, t);
     // an equal t is the only case that needs the primitive ids (the later leaf in the reference's visit order wins), so
     // the slot -> id table is read there and once at the end, not on every accepted hit
     if (hit && t == s.h.t && s.h.slot >= 0) hit = sc.leaf_prims[slot] >= sc.leaf_prims[s.h.slot];
     if (hit) { s.h.t = t; s.h.slot = slot; }
     s.cur = rem ? ~(((slot + 1) << 3) | (rem - 1)) : stack.pop();
 }
-// One trip = one memory round trip for the whole wave: every lane requests 64 bytes from what it stands on at the top of
-// the trip -- its node, or its 32-byte leaf and whatever follows it (the leaf table ends in one spare entry) -- and only
-// then do the two arms run.  Written as `if (node) { load; test } else { load; test }` the compiler waits for each arm's
-// own load inside the arm (and moves shared loads into the arms if they are not pinned), so a wave with lanes in both
-// phases pays two dependent round trips per trip.
+// One trip = one memory round trip for the whole wave: every lane requests the 64 bytes it stands on at the top of the
+// trip (a node or a leaf, through one address), and only then do the two arms run.  Written as
+// `if (node) { load; test } else { load; test }` the compiler waits for each arm's own load inside the arm (and moves
+// shared loads into the arms if they are not pinned), so a wave with lanes in both phases pays two dependent round
+// trips per trip.
 template <int KINDS = RTC_KIND_ALL, typename Stack, typename MediumFn>
 RT_DEV HitS bvh_closest_hit(const SceneT<float> &sc, const RayT<float> &r, float tmin, float tmax, Stack &stack, MediumFn &&medium, int src_slot = -1) {
     BvhTrav s; bvh_begin(s, r, tmax, src_slot);
@@ -333,7 +322,8 @@ RT_DEV HitS bvh_closest_hit(const SceneT<float> &sc, const RayT<float> &r, float
             bvh_node_step(nd, s, tmin, stack);
         } else {
             BLeaf lf;
-            lf.d[0] = q0.x; lf.d[1] = q0.y; lf.d[2] = q0.z; lf.d[3] = q0.w; lf.d[4] = q1.x; lf.d[5] = q1.y; lf.d[6] = q1.z; lf.meta = __float_as_uint(q1.w);
+            lf.d[0] = q0.x; lf.d[1] = q0.y; lf.d[2] = q0.z; lf.d[3] = q0.w; lf.d[4] = q1.x; lf.d[5] = q1.y; lf.d[6] = q1.z; lf.d[7] = q1.w;
+            lf.d[8] = q2.x; lf.d[9] = q2.y; lf.d[10] = q2.z; lf.d[11] = q2.w; lf.d[12] = q3.x; lf.d[13] = q3.y; lf.d[14] = q3.z; lf.meta = __float_as_uint(q3.w);
             bvh_leaf_step<KINDS>(sc, lf, s, tmin, stack, medium);
         }
     }

@@ -134,11 +134,17 @@ struct NoMedium32 {
     __device__ bool operator()(int, const RayT<float> &, float, float &) const { return false; }
     __device__ bool sphere_bounded(const float *, const RayT<float> &, float, float &) const { return false; }
 };
-struct MediumSampler {
+// GENERAL = false: only sphere-bounded media (their BLeaf carries the boundary); no boundary-list queries, and no cached
+// Philox block -- a ray meets few media, and the five registers decide the occupancy of the traversal kernel.
+template <bool GENERAL> struct MediumSamplerT {
     const SceneT<float> *sc; const RayT<float> *ray; float tmin; uint32_t pixel, sample, bounce, k0, k1; int draws;
-    Rng4 blk; int blk_id = -1;                                        // the Philox block the last draw came from
+    Rng4 blk; int blk_id = -1;                                        // GENERAL: the Philox block the last draw came from
     __device__ float draw() {
         const int k = draws++;
+        if (!GENERAL) {
+            const Rng4 b = rng_block(pixel, sample, RT_TAG_MEDIA | (bounce << 8) | (uint32_t)(k >> 2), k0, k1);
+            return (k & 3) == 0 ? b.x : ((k & 3) == 1 ? b.y : ((k & 3) == 2 ? b.z : b.w));
+        }
         if ((k >> 2) != blk_id) { blk_id = k >> 2; blk = rng_block(pixel, sample, RT_TAG_MEDIA | (bounce << 8) | (uint32_t)blk_id, k0, k1); }
         return (k & 3) == 0 ? blk.x : ((k & 3) == 1 ? blk.y : ((k & 3) == 2 ? blk.z : blk.w));
     }
@@ -156,6 +162,7 @@ struct MediumSampler {
     }
     __device__ bool operator()(int prim, float tmax, float &t_out) { return (*this)(prim, *ray, tmax, t_out); }
     __device__ bool operator()(int prim, const RayT<float> &r, float tmax, float &t_out) {
+        if (!GENERAL) return false;
         const PrimT<float> &p = sc->prims[prim];
         NoMedium32 nv;
         const float inf = Mth<float>::inf();
@@ -183,6 +190,7 @@ struct MediumSampler {
         return free_flight(t1, t2, tmax, __builtin_amdgcn_sqrtf(a), d[4], t_out);
     }
 };
+using MediumSampler = MediumSamplerT<true>;
 
 // ---- light list pdf / sampling (hittable_list.c:165-180, hittable.c:760-864) -------------------------
 RT_DEV float light_pdf_one(const LightT<float> &l, f3 o, f3 v) {

@@ -352,17 +352,13 @@ void to_world_point(const double M[9], const double b[3], const double p[3], dou
 
 // Traversal leaves of the FP32 production BVH (rtc_tables.h BLeaf), one per slot of leaf_prims.
 void build_bleaves(FlatScene &fs) {
-    fs.bleaves.clear(); fs.bxforms.clear();
+    fs.bleaves.clear();
     fs.media_kind = 0; fs.leaf_kinds = 0;
-    BXform ident; for (int i = 0; i < 9; i++) ident.m[i] = (i % 4 == 0); ident.b[0] = ident.b[1] = ident.b[2] = 0;
-    fs.bxforms.push_back(ident);
-    std::map<int, int> xform_of_chain;
     for (int id : fs.leaf_prims) {
         const PrimT<double> &p = fs.prims[id];
         BLeaf L; std::memset(&L, 0, sizeof L);
         double M[9], b[3]; bool wrapped, flip;
         collapse_chain(fs, p.chain, M, b, wrapped, flip);
-        uint32_t xform = 0;
         if (p.type == RTC_PRIM_SPHERE) {
             double cw[3]; to_world_point(M, b, p.d, cw);
             for (int k = 0; k < 3; k++) L.d[k] = (float)cw[k];
@@ -373,16 +369,14 @@ void build_bleaves(FlatScene &fs) {
             for (int k = 0; k < 3; k++) { const double B = (c1[k] - c0[k]) / (t1 - t0); L.d[3 + k] = (float)B; L.d[k] = (float)(c0[k] - B * t0); }
             L.d[6] = (float)p.d[8];
         } else if (p.type == RTC_PRIM_RECT) {
+            // x_obj = M x_w + b: the plane x_obj[n] = k is row_n(M) . x_w = k - b[n]; same for the two in-plane intervals
+            const int n = p.axis == RTC_AXIS_XY ? 2 : (p.axis == RTC_AXIS_XZ ? 1 : 0);
+            const int ia = p.axis == RTC_AXIS_YZ ? 1 : 0, ib = p.axis == RTC_AXIS_XY ? 1 : 2;
             const int a0 = p.axis == RTC_AXIS_YZ ? 2 : 0, b0 = p.axis == RTC_AXIS_XY ? 2 : 4;   // slots of lo_a / lo_b in d[]
-            L.d[0] = (float)p.d[6]; L.d[1] = (float)p.d[a0]; L.d[2] = (float)p.d[b0]; L.d[3] = (float)p.d[a0 + 1]; L.d[4] = (float)p.d[b0 + 1];
-            if (wrapped) {
-                auto it = xform_of_chain.find(p.chain);
-                if (it != xform_of_chain.end()) xform = (uint32_t)it->second;
-                else {
-                    BXform x; for (int i = 0; i < 9; i++) x.m[i] = (float)M[i]; for (int i = 0; i < 3; i++) x.b[i] = (float)b[i];
-                    xform = (uint32_t)fs.bxforms.size(); fs.bxforms.push_back(x); xform_of_chain[p.chain] = (int)xform;
-                }
-            }
+            for (int k = 0; k < 3; k++) { L.d[k] = (float)M[3 * n + k]; L.d[4 + k] = (float)M[3 * ia + k]; L.d[8 + k] = (float)M[3 * ib + k]; }
+            L.d[3] = (float)(p.d[6] - b[n]);
+            L.d[7] = (float)(p.d[a0] - b[ia]); L.d[12] = (float)(p.d[a0 + 1] - b[ia]);
+            L.d[11] = (float)(p.d[b0] - b[ib]); L.d[13] = (float)(p.d[b0 + 1] - b[ib]);
         }
         uint32_t sphere_medium = 0;
         if (p.type == RTC_PRIM_MEDIUM && p.bnd_count == 1 && fs.bprims[p.bnd_first].type == RTC_PRIM_SPHERE) {
@@ -400,7 +394,7 @@ void build_bleaves(FlatScene &fs) {
         if (p.type == RTC_PRIM_MEDIUM) fs.media_kind = std::max(fs.media_kind, sphere_medium ? 1 : 2);
         const MaterialT<double> &pm = fs.materials[p.mat];
         const uint32_t tex_kind = pm.tex >= 0 ? (uint32_t)fs.textures[pm.tex].type : 0u;
-        L.meta = (uint32_t)p.type | ((uint32_t)p.axis << 2) | ((uint32_t)pm.type << 4) | sphere_medium | (tex_kind << 8) | (xform << 12);
+        L.meta = (uint32_t)p.type | ((uint32_t)p.axis << 2) | ((uint32_t)pm.type << 4) | sphere_medium | (tex_kind << 8);
         fs.bleaves.push_back(L);
     }
 }

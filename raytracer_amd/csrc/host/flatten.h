@@ -20,7 +20,6 @@ struct FlatScene {
     std::vector<BvhNode> nodes;
     std::vector<int> leaf_prims;
     std::vector<BLeaf> bleaves;     // FP32 traversal leaves, one per slot of leaf_prims
-    std::vector<BXform> bxforms;    // [0] = identity
     int bvh_depth = 0;              // levels of the production BVH (root = 1): bounds the traversal stack
     std::vector<RefStep> ref_steps; // the reference's own traversal, depth-first (FP64 check path)
     std::vector<double> ref_boxes;  // 6 doubles per RTC_STEP_NODE

@@ -35,7 +35,7 @@ typedef struct rt_scene_view {
 enum { RT_SCENE_SIMPLE = 0, RT_SCENE_CORNELL = 1, RT_SCENE_FINAL = 2, RT_SCENE_BOOK1 = 3,
        RT_SCENE_CORNELL02 = 4, RT_SCENE_CORNELL_SMOKE = 5, RT_SCENE_TWO_SPHERES = 6,
        RT_SCENE_TWO_PERLIN = 7, RT_SCENE_SIMPLE_LIGHT = 8, RT_SCENE_BOOK2_RANDOM = 9,
-       RT_SCENE_MILLION = 10, RT_SCENE_EARTH = 11, RT_SCENE_FINAL_EARTH = 12 };
+       RT_SCENE_MILLION = 10, RT_SCENE_EARTH = 11, RT_SCENE_FINAL_EARTH = 12, RT_SCENE_BOX_FIELD = 13 };
 #endif
 
 static vec3 sv3(double x, double y, double z) { vec3 v; v.x = x; v.y = y; v.z = z; return v; }
@@ -204,6 +204,36 @@ static hittable_list *scene_cornell02(int smoke, rt_scene_view *v) {
     return world;
 }
 
+/* Not a scene of the reference: the 02 Cornell room (main.c:186-199) filled with 18 boxes under rotate_x / rotate_y /
+ * rotate_z + translate and 8 spheres.  114 leaves, so it is flattened into a BVH whose rect leaves are ROTATED -- the
+ * case none of the reference's own scenes puts into a BVH.  Deterministic (no rand()). */
+static hittable_list *scene_box_field(rt_scene_view *v) {
+    hittable_list *world = hittable_list_new(1024);
+    material *red = material_lambertian_new_from_color(sv3(0.65, 0.05, 0.05));
+    material *white = material_lambertian_new_from_color(sv3(0.73, 0.73, 0.73));
+    material *green = material_lambertian_new_from_color(sv3(0.12, 0.45, 0.15));
+    material *lamp = material_light_new_from_color(sv3(15, 15, 15));
+    material *steel = material_metal_new(sv3(0.8, 0.85, 0.88), 0.1);
+    material *glass = material_dielectric_new(1.5);
+    hittable_rect_new(world, 0, 0, 0, 555, 0, 555, 555, YZ, green);
+    hittable_rect_new(world, 0, 0, 0, 555, 0, 555, 0, YZ, red);
+    hittable_rect_new(world, 163, 393, 0, 0, 177, 382, 554, XZ, lamp);
+    hittable_rect_new(world, 0, 555, 0, 0, 0, 555, 0, XZ, white);
+    hittable_rect_new(world, 0, 555, 0, 0, 0, 555, 555, XZ, white);
+    hittable_rect_new(world, 0, 555, 0, 555, 0, 0, 555, XY, white);
+    for (int i = 0; i < 18; i++) {
+        const int gx = i % 6, gz = i / 6;
+        const double w = 40 + 7 * ((i * 5) % 4), hgt = 50 + 23 * ((i * 7) % 5), dep = 40 + 9 * ((i * 3) % 4);
+        hittable *b = hittable_box_new(NULL, sv3(0, 0, 0), sv3(w, hgt, dep), i % 5 == 0 ? steel : white);
+        b = hittable_rotate_init(NULL, b, -40.0 + 13.0 * ((i * 11) % 7), i % 3 == 0 ? Y : (i % 3 == 1 ? X : Z));
+        hittable_translate_init(world, b, sv3(45 + 85 * gx, 20 + 30 * (i % 2), 120 + 150 * gz));
+    }
+    for (int i = 0; i < 8; i++)
+        hittable_sphere_new(world, sv3(70 + 60 * i, 330 + 25 * (i % 3), 200 + 35 * ((i * 3) % 5)), 22 + 3 * (i % 4), i % 2 ? glass : steel);
+    view_cornell(v); v->integrator = 1; v->max_depth = 8;
+    return world;
+}
+
 /* 02 main.c:132-176 -- checker / perlin / simple-light scenes */
 static hittable_list *scene_two_spheres(rt_scene_view *v) {
     hittable_list *world = hittable_list_new(1024);
@@ -323,6 +353,7 @@ hittable_list *rt_scene_build(int id, int arg, hittable_list *lights, rt_scene_v
     case RT_SCENE_SIMPLE_LIGHT: return scene_perlin(1, view);
     case RT_SCENE_BOOK2_RANDOM: return scene_book2_random(view);
     case RT_SCENE_MILLION: return scene_million(arg > 0 ? arg : 1000, view);
+    case RT_SCENE_BOX_FIELD: return scene_box_field(view);
     default: return NULL;
     }
 }

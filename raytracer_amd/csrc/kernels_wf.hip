@@ -83,9 +83,7 @@ __global__ void __launch_bounds__(256) k_wf_init(CameraT<float> cam, RenderParam
 // 6 waves per SIMD (80 VGPRs, 4 spilled in the medium path): +3 % over the uncapped 88; 8 waves (24 spilled) is slower
 // MEDIA (SceneT::media_kind) keeps the boundary-list loops of a general constant medium, and the Philox draws of any
 // medium, out of the kernels of scenes that have none.
-struct MediumSphereOnly : MediumSampler {
-    __device__ bool operator()(int, const RayT<float> &, float, float &) { return false; }
-};
+using MediumSphereOnly = MediumSamplerT<false>;
 template <int MEDIA> struct WfMedium;
 template <> struct WfMedium<0> { using type = NoMedium32; };
 template <> struct WfMedium<1> { using type = MediumSphereOnly; };
@@ -96,7 +94,7 @@ constexpr int kWfStripes = 64;   // cache lines each statistic is striped over
 #endif
 constexpr int kWfExtendBlock = RT_WF_EXTEND_BLOCK;
 template <int MEDIA, int KINDS>
-__global__ void __launch_bounds__(kWfExtendBlock) __attribute__((amdgpu_waves_per_eu(KINDS == RTC_KIND_SPHERE ? 8 : 6))) k_wf_extend(SceneT<float> sc, RenderParams P, WfBuffers B, int cur, unsigned n_list) {
+__global__ void __launch_bounds__(kWfExtendBlock) __attribute__((amdgpu_waves_per_eu(MEDIA == 2 ? 6 : 8))) k_wf_extend(SceneT<float> sc, RenderParams P, WfBuffers B, int cur, unsigned n_list) {
     extern __shared__ int lds_stack[];                               // sc.bvh_depth entries per lane
     const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
     const int slot = i < n_list ? B.active[cur][i] : -1;

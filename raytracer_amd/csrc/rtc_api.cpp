@@ -40,7 +40,7 @@ struct DevBuf {
 };
 
 template <typename R> struct DeviceTables {
-    DevBuf prims, bprims, ops, chains, materials, textures, lights, perlin_vec, perlin_perm, images, image_data, nodes, leaf_prims, bleaves, bxforms, ref_steps, ref_boxes;
+    DevBuf prims, bprims, ops, chains, materials, textures, lights, perlin_vec, perlin_perm, images, image_data, nodes, leaf_prims, bleaves, ref_steps, ref_boxes;
     SceneT<R> view;
     bool ready = false;
 };
@@ -64,11 +64,7 @@ template <typename R> hipError_t upload_tables(const FlatScene &fs, DeviceTables
     UP(prims, prims); UP(bprims, bprims); UP(ops, ops); UP(chains, fs.chains); UP(materials, mats); UP(textures, texs); UP(lights, lights);
     UP(perlin_vec, pvec); UP(perlin_perm, fs.perlin_perm); UP(images, fs.images); UP(image_data, fs.image_data); UP(nodes, fs.nodes); UP(leaf_prims, fs.leaf_prims);
     if (with_ref_steps) { UP(ref_steps, fs.ref_steps); UP(ref_boxes, fs.ref_boxes); }
-    else {
-        // one zeroed leaf past the end: the traversal fetches 64 bytes from whatever a lane stands on (bvh_closest_hit)
-        std::vector<BLeaf> padded(fs.bleaves); BLeaf z; std::memset(&z, 0, sizeof z); padded.push_back(z);
-        UP(bleaves, padded); UP(bxforms, fs.bxforms);
-    }
+    else UP(bleaves, fs.bleaves);
 #undef UP
     SceneT<R> &v = dt.view;
     v.prims = (const PrimT<R> *)dt.prims.p; v.n_prims = (int)fs.prims.size();
@@ -80,7 +76,7 @@ template <typename R> hipError_t upload_tables(const FlatScene &fs, DeviceTables
     v.perlin_vec = (const R *)dt.perlin_vec.p; v.perlin_perm = (const int *)dt.perlin_perm.p;
     v.images = (const ImageDesc *)dt.images.p; v.image_data = (const unsigned char *)dt.image_data.p;
     v.nodes = (const BvhNode *)dt.nodes.p; v.leaf_prims = (const int *)dt.leaf_prims.p; v.n_nodes = (int)fs.nodes.size();
-    v.bleaves = (const BLeaf *)dt.bleaves.p; v.bxforms = (const BXform *)dt.bxforms.p;
+    v.bleaves = (const BLeaf *)dt.bleaves.p;
     v.ref_steps = (const RefStep *)dt.ref_steps.p; v.ref_boxes = (const double *)dt.ref_boxes.p;
     v.n_ref_steps = with_ref_steps ? (int)fs.ref_steps.size() : 0;
     v.bvh_depth = fs.bvh_depth < 1 ? 1 : (fs.bvh_depth > RTC_BVH_MAX_DEPTH ? RTC_BVH_MAX_DEPTH : fs.bvh_depth);
@@ -204,13 +200,13 @@ int rtc_scene_bvh_info(const rtc_scene *scene, long long *out4) {
     return RTC_OK;
 }
 
-int rtc_scene_dump_bvh(const rtc_scene *scene, void *nodes16, int node_cap, void *leaves8, int *prim_of_slot, int leaf_cap) {
+int rtc_scene_dump_bvh(const rtc_scene *scene, void *nodes16, int node_cap, void *leaves16, int *prim_of_slot, int leaf_cap) {
     if (!scene) return fail(RTC_ERR_ARG, "rtc_scene_dump_bvh: null scene");
     const FlatScene &fs = scene->flat;
-    static_assert(sizeof(BvhNode) == 64 && sizeof(BLeaf) == 32, "table layout");
+    static_assert(sizeof(BvhNode) == 64 && sizeof(BLeaf) == 64, "table layout");
     if (nodes16) std::memcpy(nodes16, fs.nodes.data(), std::min((size_t)(node_cap > 0 ? node_cap : 0), fs.nodes.size()) * sizeof(BvhNode));
     const size_t nl = std::min((size_t)(leaf_cap > 0 ? leaf_cap : 0), fs.bleaves.size());
-    if (leaves8) std::memcpy(leaves8, fs.bleaves.data(), nl * sizeof(BLeaf));
+    if (leaves16) std::memcpy(leaves16, fs.bleaves.data(), nl * sizeof(BLeaf));
     if (prim_of_slot) std::memcpy(prim_of_slot, fs.leaf_prims.data(), nl * sizeof(int));
     return (int)fs.bleaves.size();
 }

@@ -39,19 +39,19 @@ struct ImageDesc { int width, height; uint32_t offset, pad; };                  
 struct alignas(16) BvhNode { float lo0[3]; int child0; float hi0[3]; int count0; float lo1[3]; int child1; float hi1[3]; int count1; };
 enum { RTC_BVH_EMPTY = (int)0x80000000, RTC_BVH_MAX_DEPTH = 64 };
 inline int rtc_leaf_ref(int first, int count) { return ~((first << 3) | (count - 1)); }
-// Traversal leaf of the FP32 production BVH: 32 bytes (two dwordx4 loads), stored in BVH leaf order (slot s of bleaves
-// is primitive leaf_prims[s]).  Rigid wrappers (translate / rotate) are applied to spheres at flatten time, so spheres
-// are always in world space; a rect under a rotation keeps its object space and names the collapsed map (bxforms).
-//   sphere : d = cx cy cz r                                (world space)
-//   msphere: d = A(3) B(3) r,  centre(time) = A + B * time  (world space; moving_sphere_center, hittable.c:455-458)
-//   rect   : d = k lo_a lo_b hi_a hi_b   (a,b = in-plane axes: XY->x,y  XZ->x,z  YZ->y,z)
-//   medium : boundary = one sphere (meta bit 7): d = cx cy cz r neg_inv_density (world space);
+// Traversal leaf of the FP32 production BVH: 64 bytes, the size of a node, so a lane fetches "what it stands on" with the
+// same four 16-byte loads whether that is a node or a leaf.  Stored in BVH leaf order (slot s of bleaves is primitive
+// leaf_prims[s]).  Rigid wrappers (translate / rotate) are folded in at flatten time: every leaf is in WORLD space.
+//   sphere : d = cx cy cz r
+//   msphere: d = A(3) B(3) r,  centre(time) = A + B * time   (moving_sphere_center, hittable.c:455-458)
+//   rect   : a quad: d = N(3) k | U(3) a_lo | V(3) b_lo | a_hi b_hi -- plane N.x = k, in-plane coordinates a = U.x, b = V.x
+//            with N, U, V the rows of the collapsed rotation (unit axes for an unrotated rect, so the test is then exactly
+//            rect_hit's: (k - o_n) / d_n and the two interval checks)
+//   medium : boundary = one sphere (meta bit 7): d = cx cy cz r neg_inv_density;
 //            any other boundary: nothing here, the record is prims[leaf_prims[s]]
 // meta: bits 0-1 RTC_PRIM_*, bits 2-3 rect axis, bits 4-6 material type, bit 7 sphere-bounded medium, bits 8-9 texture
-//       type of the material (material + texture type = the ray regrouping key of the wavefront shade stage),
-//       bits 12.. xform id
-struct alignas(32) BLeaf { float d[7]; uint32_t meta; };
-struct BXform { float m[9]; float b[3]; };   // x_obj = M x_world + b
+//       type of the material (material + texture type = the ray regrouping key of the wavefront shade stage)
+struct alignas(64) BLeaf { float d[15]; uint32_t meta; };
 
 // One step of the REFERENCE's own traversal -- the hittable_list scan (hittable_list.c:125-143) with bvh_node_hit's
 // recursion (hittable.c:485-490) unrolled depth-first, left subtree before right.  Used by the FP64 check path only: the
@@ -72,7 +72,7 @@ template <typename R> struct SceneT {
     const R *perlin_vec;     const int *perlin_perm;   // per noise slot: 768 reals, 768 ints
     const ImageDesc *images; const unsigned char *image_data;
     const BvhNode *nodes;    const int *leaf_prims; int n_nodes;   // n_nodes == 0: brute-force loop over prims
-    const BLeaf *bleaves;    const BXform *bxforms;                // FP32 production BVH only (NULL in the FP64 tables)
+    const BLeaf *bleaves;                                          // FP32 production BVH only (NULL in the FP64 tables)
     int bvh_depth;           // levels of the BVH = entries the traversal stack needs
     const RefStep *ref_steps; const double *ref_boxes; int n_ref_steps;   // FP64 check path; boxes = min xyz, max xyz
     int n_media;             // media among prims (stochastic hits)

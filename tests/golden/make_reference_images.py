@@ -30,6 +30,7 @@ JOBS = [  # name, stage, scene, aspect, W, H, spp
     ("two_spheres_128", 2, "two_spheres", 0.0, 128, 72, 512),
     ("earth_128", 2, "earth", 0.0, 128, 72, 512),
     ("final_earth_96", 2, "final_earth", 0.0, 96, 96, 1024),
+    ("box_field_96", 2, "box_field", 0.0, 96, 96, 2048),          # not a reference scene: rotated rects inside a BVH
 ]
 
 

@@ -1,4 +1,4 @@
-"""CPU: the host half of the production BVH (flatten.cpp: binned-SAH builder, 32-byte world-space traversal leaves), checked
+"""CPU: the host half of the production BVH (flatten.cpp: binned-SAH builder, 64-byte world-space traversal leaves), checked
 without a GPU through rtc_scene_flatten_only + rtc_scene_dump_bvh.
 
  * structure: every leaf slot is referenced by exactly one leaf run, every inner node by exactly one parent, the depth
@@ -50,7 +50,7 @@ def walk(nodes_i, nodes_f, n_leaves):
 def brute_force(leaves_u, prims, rays, tmin=1e-3):
     """Closest hit over all traversal leaves in float64 arithmetic on the FP32 table values; ties -> highest primitive id."""
     lf = leaves_u.view(np.float32).astype(np.float64)
-    meta = leaves_u[:, 7]
+    meta = leaves_u[:, 15]
     o, d, tm = rays[:, None, 0:3], rays[:, None, 3:6], rays[:, None, 6]
     n, m = len(rays), len(lf)
     t_all = np.full((n, m), np.inf)
@@ -73,19 +73,14 @@ def brute_force(leaves_u, prims, rays, tmin=1e-3):
         t = np.where(t0 >= tmin, t0, np.where(t1 >= tmin, t1, np.inf))
         t_all[:, idx] = np.where(disc >= 0, t, np.inf)
     idx = np.nonzero(typ == 2)[0]
-    if len(idx):
-        assert (meta[idx] >> 12 == 0).all(), "this check only handles rects in world space"
+    if len(idx):                                                 # quads: plane N.x = k, a = U.x in [a_lo, a_hi], b = V.x in [b_lo, b_hi]
         L = lf[idx]
-        axis = (meta[idx] >> 2) & 3                              # XY, XZ, YZ
-        nrm = np.array([2, 1, 0])[axis]
-        ia = np.array([0, 0, 1])[axis]
-        ib = np.array([1, 2, 2])[axis]
-        on, dn = np.take_along_axis(o[:, 0], nrm[None, :].repeat(n, 0), 1), np.take_along_axis(d[:, 0], nrm[None, :].repeat(n, 0), 1)
+        N, U, V = L[None, :, 0:3], L[None, :, 4:7], L[None, :, 8:11]
         with np.errstate(divide="ignore", invalid="ignore"):
-            t = (L[None, :, 0] - on) / dn
-        pa = np.take_along_axis(o[:, 0], ia[None, :].repeat(n, 0), 1) + t * np.take_along_axis(d[:, 0], ia[None, :].repeat(n, 0), 1)
-        pb = np.take_along_axis(o[:, 0], ib[None, :].repeat(n, 0), 1) + t * np.take_along_axis(d[:, 0], ib[None, :].repeat(n, 0), 1)
-        ok = (t >= tmin) & (pa >= L[None, :, 1]) & (pa <= L[None, :, 3]) & (pb >= L[None, :, 2]) & (pb <= L[None, :, 4])
+            t = (L[None, :, 3] - (N * o).sum(-1)) / (N * d).sum(-1)
+            p = o + t[..., None] * d
+            pa, pb = (U * p).sum(-1), (V * p).sum(-1)
+        ok = (t >= tmin) & (pa >= L[None, :, 7]) & (pa <= L[None, :, 12]) & (pb >= L[None, :, 11]) & (pb <= L[None, :, 13])
         t_all[:, idx] = np.where(ok, t, np.inf)
     best = t_all.min(axis=1)
     tie = np.isclose(t_all, best[:, None], rtol=1e-12, atol=0) & np.isfinite(t_all)
@@ -93,7 +88,7 @@ def brute_force(leaves_u, prims, rays, tmin=1e-3):
     return np.where(np.isfinite(best), prim, -1), best
 
 
-@pytest.mark.parametrize("name,arg", [("book1", 0), ("final", 0), ("book2_random", 0), ("million", 40)])
+@pytest.mark.parametrize("name,arg", [("book1", 0), ("final", 0), ("book2_random", 0), ("million", 40), ("box_field", 0)])
 def test_bvh_structure_and_leaf_geometry(rtc, oracle_lib, name, arg):
     sc, cam, view = rtc.build_named_scene(name, arg=arg, host_only=True)
     try:
@@ -106,7 +101,7 @@ def test_bvh_structure_and_leaf_geometry(rtc, oracle_lib, name, arg):
         assert (leaf_refs == 1).all() and (node_refs == 1).all()
         assert depth <= info["depth"] <= 64
         lf = leaves_u.view(np.float32)
-        typ = leaves_u[:, 7] & 3
+        typ = leaves_u[:, 15] & 3
         for s in np.nonzero(typ == 0)[0][:500]:                              # spheres: centre +- r inside the parent's child box
             lo, hi = boxes[s]
             c, r = lf[s, 0:3], abs(lf[s, 3])

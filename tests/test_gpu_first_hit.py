@@ -23,6 +23,7 @@ FIXTURES = {
     "cornell02": ("cornell02", None, 2), "cornell_smoke": ("cornell_smoke", None, 2), "book2_random": ("book2_random", None, 2),
     "two_perlin": ("two_perlin", None, 2), "simple_light": ("simple_light", None, 2), "two_spheres": ("two_spheres", None, 2),
     "earth": ("earth", None, 2), "final_earth": ("final_earth", None, 2),
+    "box_field": ("box_field", None, 2),                         # not a reference scene: rotated rects inside a BVH
 }
 EXACT_COLS = [0, 1, 2, 3, 4, 5, 6, 7, 10, 11]   # hit, t, p, normal, front_face, material type
 
@@ -157,7 +158,7 @@ def test_million_sphere_bvh_against_oracle_subset(gpu, oracle_lib):
         sc.close()
 
 
-@pytest.mark.parametrize("name,spread", [("cornell", 600.0), ("final", 900.0), ("book1", 12.0), ("book2_random", 12.0)])
+@pytest.mark.parametrize("name,spread", [("cornell", 600.0), ("final", 900.0), ("book1", 12.0), ("book2_random", 12.0), ("box_field", 600.0)])
 def test_production_fp32_traversal_agrees_with_fp64(gpu, name, spread):
     """rtc_first_hit_f32 = the traversal the path tracer really runs (scalar brute-force loop / flattened BVH + LDS stack).
     Stated tolerance against the bit-exact FP64 path on 40k random rays: same primitive for >= 99.5 % of the rays;

@@ -35,6 +35,9 @@ TOL = {
     "two_spheres_128":   ("two_spheres",   None,   (0.0100, 0.0025, 0.005)),
     "earth_128":         ("earth",         None,   (0.0040, 0.0010, 0.005)),   # image texture (texture.c:136-152)
     "final_earth_96":    ("final_earth",   None,   (0.0320, 0.0080, 0.010)),   # BASELINE config 3 with the earth-map globe
+    # not a reference scene: rotated rects in a BVH.  Bright lamp, no light sampling in 02: the fixture's own noise at
+    # 2048 spp is RMSE 0.034 (a 2048-spp GPU render against a 32768-spp one: 0.0341); measured against it 0.0338 / 0.0088
+    "box_field_96":      ("box_field",     None,   (0.0400, 0.0105, 0.010)),
 }
 LUMA = np.array([0.2126, 0.7152, 0.0722])
 

@@ -123,6 +123,21 @@ int rtc_render_stats(const rtc_scene *scene, void *stream, rtc_stats *out);
 int rtc_tonemap_u8_device(const float *accum_rgba_device, int width, int height, unsigned char *rgb_u8_device, void *stream);
 int rtc_tonemap_u8(const float *accum_rgba_host, int width, int height, unsigned char *rgb_u8_host);
 
+/* ---- library facade: the three calls of the reference's library build (src/renderer.h:56-63, `make lib`
+ * Makefile:55-62) over the entry points above.  scene_settings is renderer.h:31-36; a render is `iterations` passes
+ * of `samples_per_pixel` samples (renderer.c:372-375) accumulated into one image and written as a PNG
+ * (renderer.c:429).  make_scene: `size` is the reference's table capacity, unused here; NULL on failure
+ * (rtc_last_error()).  Scene conventions of 03 main.c: black background, shutter 0..1, depth 10, mixture PDF 0.1.
+ * render_scene_accumulate has no counterpart in the reference: passes [first, first + n) added to a caller-owned host
+ * accumulator (W*H float4), so that a render can be resumed or previewed between passes. */
+typedef struct scene_settings { int res_width, res_height, samples_per_pixel, iterations; } scene_settings;
+typedef rtc_scene scene;
+scene *make_scene(const hittable_list *objects, const hittable_list *lights, int size);
+void   free_scene(scene *s);
+void   render_scene(const scene *s, const camera *cam, const scene_settings *settings, const char *filename);
+int    render_scene_accumulate(const scene *s, const camera *cam, const scene_settings *settings, int first_iteration,
+                               int n_iterations, float *accum_rgba_host);
+
 #ifdef __cplusplus
 }
 #endif

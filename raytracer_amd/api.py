@@ -41,6 +41,11 @@ class RtcSettings(C.Structure):
                 ("mixture_light_weight", C.c_double), ("kernel", C.c_int), ("reserved", C.c_int)]
 
 
+class SceneSettings(C.Structure):
+    """scene_settings of the library facade (reference src/renderer.h:31-36)."""
+    _fields_ = [("res_width", C.c_int), ("res_height", C.c_int), ("samples_per_pixel", C.c_int), ("iterations", C.c_int)]
+
+
 class RtcStats(C.Structure):
     _fields_ = [("samples", C.c_uint64), ("rays", C.c_uint64), ("kernel_ms", C.c_double), ("total_ms", C.c_double),
                 ("kernel_launches", C.c_int), ("kernel_used", C.c_int), ("wave_iterations", C.c_uint64)]
@@ -65,7 +70,7 @@ hittable_rotate_init hittable_constant_medium_init hittable_constant_medium_init
 hittable_free camera_new camera_free camera_fields rt_scene_build rt_scene_set_image_path rt_write_png rt_write_ppm_p3""".split()
 RTC_SYMBOLS = """rtc_init rtc_last_error rtc_device_name rtc_scene_build rtc_scene_flatten_only rtc_scene_free rtc_scene_num_prims
 rtc_scene_dump_leaves rtc_scene_bvh_info rtc_scene_dump_bvh rtc_first_hit_f64 rtc_first_hit_f32 rtc_primary_first_hit_f64 rtc_render_device rtc_render rtc_render_stats
-rtc_tonemap_u8_device rtc_tonemap_u8""".split()
+rtc_tonemap_u8_device rtc_tonemap_u8 make_scene free_scene render_scene render_scene_accumulate""".split()
 
 
 def lib():
@@ -141,6 +146,13 @@ def lib():
     L.rtc_render_stats.argtypes = [_P, _P, C.POINTER(RtcStats)]
     L.rtc_tonemap_u8_device.argtypes = [_P, C.c_int, C.c_int, _P, _P]
     L.rtc_tonemap_u8.argtypes = [_P, C.c_int, C.c_int, _P]
+    L.make_scene.restype = _P
+    L.make_scene.argtypes = [_P, _P, C.c_int]
+    L.free_scene.argtypes = [_P]
+    L.free_scene.restype = None
+    L.render_scene.argtypes = [_P, _P, C.POINTER(SceneSettings), C.c_char_p]
+    L.render_scene.restype = None
+    L.render_scene_accumulate.argtypes = [_P, _P, C.POINTER(SceneSettings), C.c_int, C.c_int, _P]
     L.srand = C.CDLL(None).srand
     _LIB = L
     return L

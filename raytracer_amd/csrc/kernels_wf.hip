@@ -143,8 +143,14 @@ __global__ void __launch_bounds__(kWfExtendBlock) __attribute__((amdgpu_waves_pe
 // (material type, texture type) of what they hit, then thread t shades the t-th entry of the sorted order.  Only slot
 // ids move (the path state stays where it is in HBM and the block's slots are neighbours, so the gathers stay inside a
 // few cache lines); a wave then runs one arm of the material switch instead of all of them.  No global atomics.
-constexpr int kWfShadeBlock = 512;
-__global__ void __launch_bounds__(kWfShadeBlock) k_wf_shade(SceneT<float> sc, CameraT<float> cam, RenderParams P, WfBuffers B, int cur, unsigned n_list) {
+#ifndef RT_WF_SHADE_BLOCK
+#define RT_WF_SHADE_BLOCK 512
+#endif
+constexpr int kWfShadeBlock = RT_WF_SHADE_BLOCK;
+#ifndef RT_WF_SHADE_WAVES
+#define RT_WF_SHADE_WAVES 5
+#endif
+__global__ void __launch_bounds__(kWfShadeBlock) __attribute__((amdgpu_waves_per_eu(RT_WF_SHADE_WAVES))) k_wf_shade(SceneT<float> sc, CameraT<float> cam, RenderParams P, WfBuffers B, int cur, unsigned n_list) {
     __shared__ unsigned key_count[32], key_start[32];
     __shared__ int sorted_slot[kWfShadeBlock];
     __shared__ unsigned sorted_index[kWfShadeBlock];

@@ -362,3 +362,36 @@ def test_full_size_million_spheres(gpu):
     ia, ib = clip01(mean_image(a)), clip01(mean_image(b))
     blk = np.sqrt(((block_means(ia) - block_means(ib)) ** 2).mean(axis=(0, 1)))
     assert blk.max() <= 0.002 and abs(sa["rays"] - sb["rays"]) <= 0.005 * sa["rays"]
+
+
+def test_library_facade_make_render_free(gpu, tmp_path):
+    """make_scene / render_scene / free_scene with scene_settings (the reference's library build, src/renderer.h:31-36,
+    56-63): 2 iterations x 8 spp use the sample indices 0..15, i.e. the 16-spp render of rtc_render, and end in a
+    vertically flipped PNG (renderer.c:429).  Two passes add their sums in another order than one pass: stated tolerance
+    1 grey level on < 1 % of the bytes.  render_scene_accumulate: passes added one by one equal both at once exactly."""
+    import ctypes as C
+    from PIL import Image
+    L = gpu.lib()
+    sc, cam, view = gpu.build_named_scene("cornell")
+    W = H = 64
+    s = L.make_scene(sc.world, sc.lights, 1024)
+    assert s, L.rtc_last_error()
+    try:
+        st = gpu.api.SceneSettings(W, H, 8, 2)
+        path = str(tmp_path / "facade.png")
+        L.render_scene(s, cam.handle, C.byref(st), path.encode())
+        png = np.asarray(Image.open(path)).astype(np.int64)
+        acc, _ = sc.render(cam, gpu.Settings(W, H, 16, 10, 0, seed=0))
+        want = gpu.tonemap_u8(acc)[::-1].astype(np.int64)
+        d = np.abs(png - want)
+        assert png.shape == (H, W, 3) and d.max() <= 1 and (d > 0).mean() < 0.01
+        a = np.zeros((H, W, 4), dtype=np.float32)
+        b = np.zeros((H, W, 4), dtype=np.float32)
+        assert L.render_scene_accumulate(s, cam.handle, C.byref(st), 0, 1, a.ctypes.data) == 0
+        assert L.render_scene_accumulate(s, cam.handle, C.byref(st), 1, 1, a.ctypes.data) == 0
+        assert L.render_scene_accumulate(s, cam.handle, C.byref(st), 0, 2, b.ctypes.data) == 0
+        assert np.array_equal(a, b) and (a[..., 3] == 16).all()
+        assert L.render_scene_accumulate(s, cam.handle, C.byref(st), -1, 1, a.ctypes.data) != 0
+    finally:
+        L.free_scene(s)
+        sc.close()

@@ -232,9 +232,28 @@ RT_DEV bool sphere_roots_f32(V3<float> c, float rad, const RayT<float> &r, float
     t = ok0 ? t0 : t1;
     return (from_here | (q >= 0.0f)) & (ok0 | ok1);
 }
-// KINDS: leaf types the scene's BVH holds (bit 0 rects, 1 spheres, 2 moving spheres; SceneT::leaf_kinds) -- a kernel for a
+// KINDS: leaf types the scene's BVH holds (bit 0 rects, 1 spheres, 2 moving spheres, 3 boxes; SceneT::leaf_kinds) -- a kernel for a
 // spheres-only scene carries no rect / transform code and fewer registers.
-enum { RTC_KIND_RECT = 1, RTC_KIND_SPHERE = 2, RTC_KIND_MSPHERE = 4, RTC_KIND_ALL = 7 };
+enum { RTC_KIND_RECT = 1, RTC_KIND_SPHERE = 2, RTC_KIND_MSPHERE = 4, RTC_KIND_BOX = 8, RTC_KIND_ALL = 15 };
+// Box record (rtc_tables.h): the ray crosses a closed box through an entry and an exit face; the list scan over its six
+// two-sided rects (hittable.c:521-523) returns the entry point if it lies in [tmin, tmax] and the exit point otherwise.
+// Each t is rect_hit's (k - o_n) / d_n on the face's own axis; `face` = 2 * axis + (hi side).  A ray that starts on a
+// face (src_face) cannot hit that face again.
+RT_DEV bool box_leaf_t(const BLeaf &lf, const RayT<float> &r, V3<float> inv, float tmin, float tmax, int src_face, float &t, int &face) {
+    const float x0 = (lf.d[0] - r.o.x) * inv.x, x1 = (lf.d[3] - r.o.x) * inv.x;
+    const float y0 = (lf.d[1] - r.o.y) * inv.y, y1 = (lf.d[4] - r.o.y) * inv.y;
+    const float z0 = (lf.d[2] - r.o.z) * inv.z, z1 = (lf.d[5] - r.o.z) * inv.z;
+    const float nx = fminf(x0, x1), ny = fminf(y0, y1), nz = fminf(z0, z1);
+    const float fx = fmaxf(x0, x1), fy = fmaxf(y0, y1), fz = fmaxf(z0, z1);
+    const float t_in = fmaxf(fmaxf(nx, ny), nz), t_out = fminf(fminf(fx, fy), fz);
+    const int ax_in = nx == t_in ? 0 : (ny == t_in ? 1 : 2), ax_out = fx == t_out ? 0 : (fy == t_out ? 1 : 2);
+    const float inv_in = ax_in == 0 ? inv.x : (ax_in == 1 ? inv.y : inv.z), inv_out = ax_out == 0 ? inv.x : (ax_out == 1 ? inv.y : inv.z);
+    const int f_in = 2 * ax_in + (inv_in > 0.0f ? 0 : 1), f_out = 2 * ax_out + (inv_out > 0.0f ? 1 : 0);
+    const bool enter = (t_in >= tmin) & (t_in <= tmax) & (f_in != src_face);
+    t = enter ? t_in : t_out;
+    face = enter ? f_in : f_out;
+    return (t_in <= t_out) & (t >= tmin) & (t <= tmax) & (face != src_face);
+}
 template <int KINDS = RTC_KIND_ALL>
 RT_DEV bool bleaf_t(const BLeaf &lf, const RayT<float> &r, float tmin, float tmax, bool from_here, float &t) {
     const uint32_t type = lf.meta & 3u;
@@ -290,17 +309,24 @@ RT_DEV void bvh_leaf_step(const SceneT<float> &sc, const BLeaf &lf, BvhTrav &s, 
     ++s.n_steps;
 #endif
     const int v = ~s.cur, slot = v >> 3, rem = v & 7;
+    int hit_slot = slot, width = 1;                              // a box record answers for six slots
     float t; bool hit;
     if ((lf.meta & 3u) == RTC_PRIM_MEDIUM) {
         if (lf.meta & 0x80u) hit = medium.sphere_bounded(lf.d, s.r, s.h.t, t);
         else hit = medium(sc.leaf_prims[slot], s.r, s.h.t, t);
     }
+    else if ((KINDS & RTC_KIND_BOX) && (lf.meta & RTC_LEAF_BOX)) {
+        const unsigned sf = (unsigned)(s.src_slot - slot);
+        int face;
+        hit = box_leaf_t(lf, s.r, s.inv, tmin, s.h.t, sf < 6u ? (int)sf : -1, t, face);
+        hit_slot = slot + face; width = 6;
+    }
     else hit = bleaf_t<KINDS>(lf, s.r, tmin, s.h.t, slot == s.src_slot, t);
     // an equal t is the only case that needs the primitive ids (the later leaf in the reference's visit order wins), so
     // the slot -> id table is read there and once at the end, not on every accepted hit
-    if (hit && t == s.h.t && s.h.slot >= 0) hit = sc.leaf_prims[slot] >= sc.leaf_prims[s.h.slot];
-    if (hit) { s.h.t = t; s.h.slot = slot; }
-    s.cur = rem ? ~(((slot + 1) << 3) | (rem - 1)) : stack.pop();
+    if (hit && t == s.h.t && s.h.slot >= 0) hit = sc.leaf_prims[hit_slot] >= sc.leaf_prims[s.h.slot];
+    if (hit) { s.h.t = t; s.h.slot = hit_slot; }
+    s.cur = rem ? ~(((slot + width) << 3) | (rem - 1)) : stack.pop();
 }
 // One trip = one memory round trip for the whole wave: every lane requests the 64 bytes it stands on at the top of the
 // trip (a node or a leaf, through one address), and only then do the two arms run.  Written as

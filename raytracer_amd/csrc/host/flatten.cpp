@@ -193,7 +193,12 @@ struct Flattener {
     bool walk(const hittable *h, bool boundary, std::vector<RefStep> *steps) {
         switch (h->kind) {
         case RT_H_SPHERE: case RT_H_MOVING_SPHERE: case RT_H_RECT: return leaf(h, boundary, steps);
-        case RT_H_BOX: for (int i = 0; i < h->members->index; i++) if (!walk(h->members->objs[i], boundary, steps)) return false; return true;
+        case RT_H_BOX: {
+            const size_t first = fs.prims.size();
+            for (int i = 0; i < h->members->index; i++) if (!walk(h->members->objs[i], boundary, steps)) return false;
+            if (!boundary && fs.prims.size() - first == 6) fs.box_first.push_back((int)first);
+            return true;
+        }
         case RT_H_BVH: {
             if (!steps) { for (int i = 0; i < h->bvh_count; i++) if (!walk(h->members->objs[h->bvh_order[i]], boundary, nullptr)) return false; return true; }
             // leaves are numbered in visit order (bvh_order); each member's own steps are kept aside and spliced into
@@ -244,11 +249,17 @@ struct Flattener {
 };
 
 // ---- binned-SAH BVH over world-space leaf boxes -------------------------------------------------
+// An item is one primitive, or one axis-aligned box whose six rects become ONE traversal record (BLeaf): the record sits
+// in the slot of face 0 and the six faces own six consecutive slots in the order x-lo x-hi y-lo y-hi z-lo z-hi, so a
+// hit on face f is reported as slot + f and shading finds the face's own rect through leaf_prims as before.
+struct BuildItem { int prim; int faces[6]; bool is_box; };
 struct Builder {
-    const std::vector<Box> &boxes;
+    const std::vector<Box> &boxes;                      // per item
     std::vector<int> idx;
     std::vector<BvhNode> &nodes;
     std::vector<int> &leaf_prims;
+    const std::vector<BuildItem> &items;
+    std::vector<int> &box_slots;
     static constexpr int kLeafMax = 4, kBins = 16;
     struct Child { int child, count; Box box; };
 
@@ -259,8 +270,13 @@ struct Builder {
 
     Child make_leaf(int lo, int hi, const Box &b) {
         Child c; c.child = (int)leaf_prims.size(); c.count = hi - lo; c.box = b;
-        for (int i = lo; i < hi; i++) leaf_prims.push_back(idx[i]);
-        std::sort(leaf_prims.end() - (hi - lo), leaf_prims.end());
+        std::sort(idx.begin() + lo, idx.begin() + hi, [&](int x, int y) { return items[x].prim < items[y].prim; });
+        for (int i = lo; i < hi; i++) {
+            const BuildItem &it = items[idx[i]];
+            if (!it.is_box) { leaf_prims.push_back(it.prim); continue; }
+            box_slots.push_back((int)leaf_prims.size());
+            for (int f = 0; f < 6; f++) leaf_prims.push_back(it.faces[f]);
+        }
         return c;
     }
     int max_depth = 0;
@@ -354,11 +370,28 @@ void to_world_point(const double M[9], const double b[3], const double p[3], dou
 void build_bleaves(FlatScene &fs) {
     fs.bleaves.clear();
     fs.media_kind = 0; fs.leaf_kinds = 0;
-    for (int id : fs.leaf_prims) {
+    std::vector<char> box_start(fs.leaf_prims.size(), 0);
+    for (int s : fs.box_slots) box_start[(size_t)s] = 1;
+    for (size_t slot = 0; slot < fs.leaf_prims.size(); slot++) {
+        const int id = fs.leaf_prims[slot];
         const PrimT<double> &p = fs.prims[id];
         BLeaf L; std::memset(&L, 0, sizeof L);
         double M[9], b[3]; bool wrapped, flip;
         collapse_chain(fs, p.chain, M, b, wrapped, flip);
+        if (box_start[slot]) {
+            // faces x-lo x-hi y-lo y-hi z-lo z-hi live in slots slot .. slot+5; M is the identity here (box_items), so the
+            // world-space planes are the object-space ones shifted by the translation: x_w = x_obj - b
+            for (int n = 0; n < 3; n++) {
+                L.d[n] = (float)(fs.prims[fs.leaf_prims[slot + 2 * n]].d[6] - b[n]);
+                L.d[3 + n] = (float)(fs.prims[fs.leaf_prims[slot + 2 * n + 1]].d[6] - b[n]);
+            }
+            const MaterialT<double> &pm = fs.materials[p.mat];
+            const uint32_t tex_kind = pm.tex >= 0 ? (uint32_t)fs.textures[pm.tex].type : 0u;
+            L.meta = (uint32_t)RTC_PRIM_RECT | ((uint32_t)p.axis << 2) | ((uint32_t)pm.type << 4) | (tex_kind << 8) | RTC_LEAF_BOX;
+            fs.leaf_kinds |= 8;
+            fs.bleaves.push_back(L);
+            continue;
+        }
         if (p.type == RTC_PRIM_SPHERE) {
             double cw[3]; to_world_point(M, b, p.d, cw);
             for (int k = 0; k < 3; k++) L.d[k] = (float)cw[k];
@@ -390,7 +423,10 @@ void build_bleaves(FlatScene &fs) {
             L.d[3] = (float)bp.d[3]; L.d[4] = (float)p.d[0];
             sphere_medium = 1u << 7;
         }
-        fs.leaf_kinds |= p.type == RTC_PRIM_RECT ? 1 : (p.type == RTC_PRIM_SPHERE ? 2 : (p.type == RTC_PRIM_MSPHERE ? 4 : 0));
+        // (the five face slots behind a box record are never reached by the traversal: they do not count as rect leaves)
+        bool behind_box = false;
+        for (size_t k = 1; k <= 5 && k <= slot; k++) behind_box |= box_start[slot - k] != 0;
+        if (!behind_box) fs.leaf_kinds |= p.type == RTC_PRIM_RECT ? 1 : (p.type == RTC_PRIM_SPHERE ? 2 : (p.type == RTC_PRIM_MSPHERE ? 4 : 0));
         if (p.type == RTC_PRIM_MEDIUM) fs.media_kind = std::max(fs.media_kind, sphere_medium ? 1 : 2);
         const MaterialT<double> &pm = fs.materials[p.mat];
         const uint32_t tex_kind = pm.tex >= 0 ? (uint32_t)fs.textures[pm.tex].type : 0u;
@@ -544,6 +580,48 @@ void build_small_pack(FlatScene &fs) {
     fs.small_any_fuzz = any_fuzz; fs.small_ok = true;
 }
 
+// Build items of the production BVH: every primitive on its own, except the six rects of a hittable box
+// (hittable.c:146-151) that sits in world space up to a translation -- those become one box item (BuildItem).
+void box_items(const FlatScene &fs, const std::vector<Box> &prim_boxes, std::vector<BuildItem> &items, std::vector<Box> &item_boxes) {
+    std::vector<int> box_of(fs.prims.size(), -1);
+    std::vector<BuildItem> boxes;
+    for (int first : fs.box_first) {
+        BuildItem it; it.prim = first; it.is_box = true;
+        for (int f = 0; f < 6; f++) it.faces[f] = -1;
+        double M[9], b[3]; bool wrapped, flip;
+        collapse_chain(fs, fs.prims[first].chain, M, b, wrapped, flip);
+        bool ok = true;
+        for (int i = 0; i < 9; i++) ok &= M[i] == (i % 4 == 0 ? 1.0 : 0.0);
+        double lo[3] = {HUGE_VAL, HUGE_VAL, HUGE_VAL}, hi[3] = {-HUGE_VAL, -HUGE_VAL, -HUGE_VAL};
+        for (int k = 0; k < 6 && ok; k++) {
+            const PrimT<double> &p = fs.prims[first + k];
+            ok &= p.type == RTC_PRIM_RECT && p.chain == fs.prims[first].chain;
+            const int n = p.axis == RTC_AXIS_XY ? 2 : (p.axis == RTC_AXIS_XZ ? 1 : 0);
+            lo[n] = std::min(lo[n], p.d[6]); hi[n] = std::max(hi[n], p.d[6]);
+        }
+        for (int k = 0; k < 6 && ok; k++) {
+            const PrimT<double> &p = fs.prims[first + k];
+            const int n = p.axis == RTC_AXIS_XY ? 2 : (p.axis == RTC_AXIS_XZ ? 1 : 0);
+            ok &= lo[n] < hi[n];
+            const int f = 2 * n + (p.d[6] == hi[n] ? 1 : 0);
+            ok &= it.faces[f] < 0;
+            it.faces[f] = first + k;
+            // each side spans the box on its two in-plane axes
+            for (int a = 0; a < 3; a++) if (a != n) ok &= p.d[2 * a] == lo[a] && p.d[2 * a + 1] == hi[a];
+        }
+        if (!ok) continue;
+        for (int k = 0; k < 6; k++) box_of[(size_t)(first + k)] = (int)boxes.size();
+        boxes.push_back(it);
+    }
+    for (size_t i = 0; i < fs.prims.size(); i++) {
+        if (box_of[i] < 0) { BuildItem it; it.prim = (int)i; it.is_box = false; for (int f = 0; f < 6; f++) it.faces[f] = -1; items.push_back(it); item_boxes.push_back(prim_boxes[i]); continue; }
+        if ((int)i != boxes[(size_t)box_of[i]].prim) continue;
+        Box bx = box_empty();
+        for (int k = 0; k < 6; k++) box_merge(bx, prim_boxes[i + (size_t)k]);
+        items.push_back(boxes[(size_t)box_of[i]]); item_boxes.push_back(bx);
+    }
+}
+
 }  // namespace
 
 bool flatten_scene(const hittable_list *world, const hittable_list *lights, const color *background,
@@ -570,8 +648,11 @@ bool flatten_scene(const hittable_list *world, const hittable_list *lights, cons
         }
     build_small_pack(out);
     if ((int)out.prims.size() > bvh_threshold) {
-        Builder b{f.prim_boxes, {}, out.nodes, out.leaf_prims};
-        b.idx.resize(out.prims.size());
+        std::vector<BuildItem> items; std::vector<Box> item_boxes;
+        box_items(out, f.prim_boxes, items, item_boxes);
+        out.box_slots.clear();
+        Builder b{item_boxes, {}, out.nodes, out.leaf_prims, items, out.box_slots};
+        b.idx.resize(items.size());
         for (size_t i = 0; i < b.idx.size(); i++) b.idx[i] = (int)i;
         out.nodes.reserve(out.prims.size());
         Builder::Child root = b.build(0, (int)b.idx.size());

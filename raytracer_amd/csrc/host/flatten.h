@@ -21,6 +21,8 @@ struct FlatScene {
     std::vector<int> leaf_prims;
     std::vector<BLeaf> bleaves;     // FP32 traversal leaves, one per slot of leaf_prims
     int bvh_depth = 0;              // levels of the production BVH (root = 1): bounds the traversal stack
+    std::vector<int> box_first;     // first primitive of every hittable box (its 6 sides follow in creation order)
+    std::vector<int> box_slots;     // leaf slots where an axis-aligned box record starts (it owns 6 slots: BLeaf, rtc_tables.h)
     std::vector<RefStep> ref_steps; // the reference's own traversal, depth-first (FP64 check path)
     std::vector<double> ref_boxes;  // 6 doubles per RTC_STEP_NODE
     // small-scene pack (empty when the scene is not eligible: see build_small_pack in flatten.cpp)

@@ -47,10 +47,15 @@ inline int rtc_leaf_ref(int first, int count) { return ~((first << 3) | (count -
 //   rect   : a quad: d = N(3) k | U(3) a_lo | V(3) b_lo | a_hi b_hi -- plane N.x = k, in-plane coordinates a = U.x, b = V.x
 //            with N, U, V the rows of the collapsed rotation (unit axes for an unrotated rect, so the test is then exactly
 //            rect_hit's: (k - o_n) / d_n and the two interval checks)
+//   box    : (rect type + meta bit 10) the six rects of an axis-aligned hittable box as one record: d = lo(3) hi(3).  The
+//            record owns SIX consecutive slots, faces x-lo x-hi y-lo y-hi z-lo z-hi; a hit on face f is slot + f, whose
+//            leaf_prims entry is that face's rect; slots 1..5 behind the record hold the faces' quads but no BVH
+//            reference reaches them
 //   medium : boundary = one sphere (meta bit 7): d = cx cy cz r neg_inv_density;
 //            any other boundary: nothing here, the record is prims[leaf_prims[s]]
 // meta: bits 0-1 RTC_PRIM_*, bits 2-3 rect axis, bits 4-6 material type, bit 7 sphere-bounded medium, bits 8-9 texture
 //       type of the material (material + texture type = the ray regrouping key of the wavefront shade stage)
+enum { RTC_LEAF_BOX = 1u << 10 };
 struct alignas(64) BLeaf { float d[15]; uint32_t meta; };
 
 // One step of the REFERENCE's own traversal -- the hittable_list scan (hittable_list.c:125-143) with bvh_node_hit's
@@ -76,7 +81,7 @@ template <typename R> struct SceneT {
     int bvh_depth;           // levels of the BVH = entries the traversal stack needs
     const RefStep *ref_steps; const double *ref_boxes; int n_ref_steps;   // FP64 check path; boxes = min xyz, max xyz
     int n_media;             // media among prims (stochastic hits)
-    int leaf_kinds;          // BVH leaves: bit 0 rects, bit 1 spheres, bit 2 moving spheres (RTC_KIND_*, rt_core.hpp)
+    int leaf_kinds;          // BVH leaves: bit 0 rects, bit 1 spheres, bit 2 moving spheres, bit 3 boxes (RTC_KIND_*, rt_core.hpp)
     int media_kind;          // BVH leaves: 0 no media, 1 sphere-bounded media only (BLeaf carries them), 2 general boundaries
     R background[3];
 };

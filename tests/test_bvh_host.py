@@ -18,8 +18,12 @@ def decode(child):
     return v >> 3, (v & 7) + 1
 
 
-def walk(nodes_i, nodes_f, n_leaves):
+BOX = 1 << 10                                                    # RTC_LEAF_BOX: one record answers for six slots
+
+
+def walk(nodes_i, nodes_f, meta):
     """-> (leaf reference count per slot, node reference count, max depth, per-slot list of enclosing boxes)"""
+    n_leaves = len(meta)
     leaf_refs = np.zeros(n_leaves, dtype=np.int64)
     node_refs = np.zeros(len(nodes_i), dtype=np.int64)
     boxes = [None] * n_leaves
@@ -41,9 +45,13 @@ def walk(nodes_i, nodes_f, n_leaves):
                 first, count = decode(child)
                 assert count == int(nodes_i[n, 7 + 8 * side])
                 max_depth = max(max_depth, depth + 1)
-                for s in range(first, first + count):
-                    leaf_refs[s] += 1
-                    boxes[s] = (lo.copy(), hi.copy())
+                s = first
+                for _ in range(count):                            # `count` records; a box record is six slots wide
+                    width = 6 if int(meta[s]) & BOX else 1
+                    for k in range(s, s + width):
+                        leaf_refs[k] += 1
+                        boxes[k] = (lo.copy(), hi.copy())
+                    s += width
     return leaf_refs, node_refs, max_depth, boxes
 
 
@@ -72,7 +80,7 @@ def brute_force(leaves_u, prims, rays, tmin=1e-3):
         t0, t1 = (-hb - sq) / a, (-hb + sq) / a
         t = np.where(t0 >= tmin, t0, np.where(t1 >= tmin, t1, np.inf))
         t_all[:, idx] = np.where(disc >= 0, t, np.inf)
-    idx = np.nonzero(typ == 2)[0]
+    idx = np.nonzero((typ == 2) & ((meta & BOX) == 0))[0]
     if len(idx):                                                 # quads: plane N.x = k, a = U.x in [a_lo, a_hi], b = V.x in [b_lo, b_hi]
         L = lf[idx]
         N, U, V = L[None, :, 0:3], L[None, :, 4:7], L[None, :, 8:11]
@@ -82,6 +90,23 @@ def brute_force(leaves_u, prims, rays, tmin=1e-3):
             pa, pb = (U * p).sum(-1), (V * p).sum(-1)
         ok = (t >= tmin) & (pa >= L[None, :, 7]) & (pa <= L[None, :, 12]) & (pb >= L[None, :, 11]) & (pb <= L[None, :, 13])
         t_all[:, idx] = np.where(ok, t, np.inf)
+    # box records: the record (slab test, entry point else exit point) answers for its six face slots
+    for s0 in np.nonzero((typ == 2) & ((meta & BOX) != 0))[0]:
+        lo, hi = lf[s0, 0:3], lf[s0, 3:6]
+        with np.errstate(divide="ignore", invalid="ignore"):
+            t0, t1 = (lo - o[:, 0]) / d[:, 0], (hi - o[:, 0]) / d[:, 0]
+        tn, tf = np.minimum(t0, t1), np.maximum(t0, t1)
+        t_in, t_out = tn.max(1), tf.min(1)
+        ax_in, ax_out = tn.argmax(1), tf.argmin(1)
+        rows = np.arange(n)
+        f_in = 2 * ax_in + (d[rows, 0, ax_in] <= 0)
+        f_out = 2 * ax_out + (d[rows, 0, ax_out] > 0)
+        enter = t_in >= tmin
+        t = np.where(enter, t_in, t_out)
+        face = np.where(enter, f_in, f_out)
+        ok = (t_in <= t_out) & (t >= tmin)
+        t_all[:, s0:s0 + 6] = np.inf
+        t_all[rows[ok], s0 + face[ok]] = t[ok]
     best = t_all.min(axis=1)
     tie = np.isclose(t_all, best[:, None], rtol=1e-12, atol=0) & np.isfinite(t_all)
     prim = np.where(tie, prims[None, :], -1).max(axis=1)
@@ -97,7 +122,7 @@ def test_bvh_structure_and_leaf_geometry(rtc, oracle_lib, name, arg):
         assert info["nodes"] == len(nodes_u) > 0 and info["leaf_slots"] == len(leaves_u) == sc.num_prims()
         assert sorted(prims.tolist()) == list(range(sc.num_prims()))       # a permutation: slot -> primitive id
         nodes_i, nodes_f = nodes_u.view(np.int32), nodes_u.view(np.float32)
-        leaf_refs, node_refs, depth, boxes = walk(nodes_i, nodes_f, len(leaves_u))
+        leaf_refs, node_refs, depth, boxes = walk(nodes_i, nodes_f, leaves_u[:, 15])
         assert (leaf_refs == 1).all() and (node_refs == 1).all()
         assert depth <= info["depth"] <= 64
         lf = leaves_u.view(np.float32)

@@ -37,8 +37,8 @@ hipError_t launch_tonemap_u8(const float4 *accum, int n_pixels, unsigned char *r
 // Path-slot state in HBM, SoA.  Slot s of layer k = s / slots_per_layer renders samples s_begin + k, + layers, ... of ONE
 // pixel (8x8 tiles, 64 consecutive slots per tile).
 struct WfBuffers {
-    float4 *ro, *rd, *thr, *sum;      // origin+time, direction, throughput, radiance sum of the slot
-    int4 *meta;                       // current sample, depth, leaf slot the ray starts on, pixel
+    float4 *ro, *rd, *tm, *sum;       // origin | time, direction | throughput.x, throughput.yz | sample + (depth << 24) | leaf slot
+                                      // the ray starts on (int bits), radiance sum of the slot; the pixel follows from the slot
     float2 *hit;                      // t, leaf slot (int bits; -1 = miss) written by extend
     unsigned char *key;               // regrouping key of the hit written by extend: material type * 4 + texture type, 31 = miss
     int *active[2];                   // slot lists (ping-pong across compactions); -1 = hole

@@ -62,9 +62,8 @@ __global__ void __launch_bounds__(256) k_wf_init(CameraT<float> cam, RenderParam
             const uint32_t pixel = (uint32_t)(py * P.width + px);
             const RayT<float> r = primary_ray(cam, P, pixel, px, py, (uint32_t)s);
             B.ro[slot] = make_float4(r.o.x, r.o.y, r.o.z, r.time);
-            B.rd[slot] = make_float4(r.d.x, r.d.y, r.d.z, 0.0f);
-            B.thr[slot] = make_float4(1, 1, 1, 0);
-            B.meta[slot] = make_int4(s, 0, -1, (int)pixel);
+            B.rd[slot] = make_float4(r.d.x, r.d.y, r.d.z, 1.0f);
+            B.tm[slot] = make_float4(1.0f, 1.0f, __int_as_float(s), __int_as_float(-1));
             live = true;
         }
         B.active[0][slot] = live ? slot : -1;
@@ -104,15 +103,18 @@ __global__ void __launch_bounds__(kWfExtendBlock) __attribute__((amdgpu_waves_pe
 #endif
     if (live) {
         const float4 o = B.ro[slot], d = B.rd[slot];
-        const int4 m = B.meta[slot];                                 // sample, depth, src slot, pixel
+        const float4 tm = B.tm[slot];                                // throughput y z, sample | depth << 24, src slot
+        const int src_slot = __float_as_int(tm.w);
         RayT<float> r; r.o = f3mk(o.x, o.y, o.z); r.d = f3mk(d.x, d.y, d.z); r.time = o.w;
         typename WfMedium<MEDIA>::type medium;
         if constexpr (MEDIA != 0) {
-            medium.sc = &sc; medium.ray = &r; medium.tmin = 0.001f; medium.pixel = (uint32_t)m.w; medium.sample = (uint32_t)m.x; medium.bounce = (uint32_t)m.y;
+            int px, py, layer; slot_pixel(P, B.slots_per_layer, slot, px, py, layer);
+            const uint32_t sd = __float_as_uint(tm.z);
+            medium.sc = &sc; medium.ray = &r; medium.tmin = 0.001f; medium.pixel = (uint32_t)(py * P.width + px); medium.sample = sd & 0xffffffu; medium.bounce = sd >> 24;
             medium.k0 = P.seed_lo; medium.k1 = P.seed_hi; medium.draws = 0;
         }
         LdsStack stack(lds_stack + threadIdx.x, kWfExtendBlock, sc.bvh_depth);
-        const HitS h = bvh_closest_hit<KINDS>(sc, r, 0.001f, Mth<float>::inf(), stack, medium, m.z);   // ray.c:56
+        const HitS h = bvh_closest_hit<KINDS>(sc, r, 0.001f, Mth<float>::inf(), stack, medium, src_slot);   // ray.c:56
         B.hit[slot] = make_float2(h.t, __int_as_float(h.slot));
         const uint32_t lm = h.slot >= 0 ? sc.bleaves[h.slot].meta : 0u;
         B.key[slot] = h.slot >= 0 ? (unsigned char)(((lm >> 4) & 7u) * 4u + ((lm >> 8) & 3u)) : (unsigned char)31;
@@ -174,13 +176,15 @@ __global__ void __launch_bounds__(kWfShadeBlock) __attribute__((amdgpu_waves_per
 #endif
     bool died = false;
     if (slot >= 0) {
-        const float4 o = B.ro[slot], d = B.rd[slot], T4 = B.thr[slot];
-        int4 m = B.meta[slot];
+        const float4 o = B.ro[slot], d = B.rd[slot], tm = B.tm[slot];
+        int px, py, layer; slot_pixel(P, B.slots_per_layer, slot, px, py, layer);
+        // sample, depth, leaf slot the ray starts on, pixel
+        int4 m = make_int4((int)(__float_as_uint(tm.z) & 0xffffffu), (int)(__float_as_uint(tm.z) >> 24), __float_as_int(tm.w), py * P.width + px);
         const float2 hh = B.hit[slot];
         const int hslot = __float_as_int(hh.y);
         PathState ps;
         ps.ray.o = f3mk(o.x, o.y, o.z); ps.ray.d = f3mk(d.x, d.y, d.z); ps.ray.time = o.w;
-        ps.T = f3mk(T4.x, T4.y, T4.z); ps.L = f3mk(0, 0, 0);
+        ps.T = f3mk(d.w, tm.x, tm.y); ps.L = f3mk(0, 0, 0);
         const uint32_t pixel = (uint32_t)m.w;
         int status;
         if (hslot < 0) {                                             // ray.c:56: background (01: sky gradient)
@@ -203,7 +207,6 @@ __global__ void __launch_bounds__(kWfShadeBlock) __attribute__((amdgpu_waves_per
             }
             m.x += B.layers;                                         // this slot's next sample
             if (m.x < P.s_end) {
-                int px, py, layer; slot_pixel(P, B.slots_per_layer, slot, px, py, layer);
                 ps.ray = primary_ray(cam, P, pixel, px, py, (uint32_t)m.x);
                 ps.T = f3mk(1, 1, 1); m.y = 0; m.z = -1;
             } else died = true;
@@ -211,9 +214,8 @@ __global__ void __launch_bounds__(kWfShadeBlock) __attribute__((amdgpu_waves_per
         if (died) B.active[cur][i] = -1;                            // stays in the list as a hole until the next compaction
         else {
             B.ro[slot] = make_float4(ps.ray.o.x, ps.ray.o.y, ps.ray.o.z, ps.ray.time);
-            B.rd[slot] = make_float4(ps.ray.d.x, ps.ray.d.y, ps.ray.d.z, 0.0f);
-            B.thr[slot] = make_float4(ps.T.x, ps.T.y, ps.T.z, 0.0f);
-            B.meta[slot] = m;
+            B.rd[slot] = make_float4(ps.ray.d.x, ps.ray.d.y, ps.ray.d.z, ps.T.x);
+            B.tm[slot] = make_float4(ps.T.y, ps.T.z, __uint_as_float((uint32_t)m.x | ((uint32_t)m.y << 24)), __int_as_float(m.z));
         }
     }
     wave_count_sub(B.counters + 0, died);
@@ -256,7 +258,7 @@ __global__ void __launch_bounds__(256) k_wf_finish(RenderParams P, WfBuffers B, 
 
 }  // namespace
 
-size_t wf_bytes_per_slot() { return 4 * sizeof(float4) + sizeof(int4) + sizeof(float2) + 2 * sizeof(int) + 1; }
+size_t wf_bytes_per_slot() { return 4 * sizeof(float4) + sizeof(float2) + 2 * sizeof(int) + 1; }
 size_t wf_stats_bytes() { return (1 + 2 * kWfStripes) * 8 * sizeof(unsigned long long); }   // cache lines of 64 bytes
 
 hipError_t launch_wf_init(const CameraT<float> &cam, const RenderParams &p, const WfBuffers &b, hipStream_t stream) {

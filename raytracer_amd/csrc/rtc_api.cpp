@@ -322,9 +322,8 @@ static int render_wavefront(rtc_scene *s, const CameraT<float> &camf, const Rend
     const size_t n = (size_t)n_slots;
     b.ro = (float4 *)base; base += n * sizeof(float4);
     b.rd = (float4 *)base; base += n * sizeof(float4);
-    b.thr = (float4 *)base; base += n * sizeof(float4);
+    b.tm = (float4 *)base; base += n * sizeof(float4);
     b.sum = (float4 *)base; base += n * sizeof(float4);
-    b.meta = (int4 *)base; base += n * sizeof(int4);
     b.hit = (float2 *)base; base += n * sizeof(float2);
     b.active[0] = (int *)base; base += n * sizeof(int);
     b.active[1] = (int *)base; base += n * sizeof(int);
@@ -374,9 +373,13 @@ int rtc_render_device(const rtc_scene *scene_c, const camera *cam, const rtc_set
     const bool small = st->kernel == 2 || (st->kernel == 0 && s->small.n_leaves > 0);
     if (small && s->small.n_leaves <= 0)
         return fail(RTC_ERR_SCENE, "kernel 2 (small-scene) needs <= 64 rect/sphere leaves with solid textures and no media");
-    const bool wavefront = st->kernel == 3 || (st->kernel == 0 && !small && s->f32.view.n_nodes > 0);
+    // the wavefront path state packs (sample, depth) into 24 + 8 bits (kernels.h WfBuffers)
+    const bool wf_fits = st->max_depth <= 255 && st->sample_end <= (1 << 24);
+    const bool wavefront = st->kernel == 3 || (st->kernel == 0 && !small && s->f32.view.n_nodes > 0 && wf_fits);
     if (wavefront && s->f32.view.n_nodes <= 0)
         return fail(RTC_ERR_SCENE, "kernel 3 (wavefront) needs a scene that was flattened into a BVH (more than 64 leaves)");
+    if (wavefront && !wf_fits)
+        return fail(RTC_ERR_ARG, "kernel 3 (wavefront) needs max_depth <= 255 and sample_end <= 2^24");
     if (small) {
         if ((size_t)p.n_tiles > s->tile_scratch_cap) {
             if (s->tile_scratch.p) { HIP_TRY(hipStreamSynchronize(stream)); (void)hipFree(s->tile_scratch.p); s->tile_scratch.p = nullptr; s->tile_scratch_cap = 0; }

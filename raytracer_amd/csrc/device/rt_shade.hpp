@@ -96,6 +96,9 @@ RT_DEV float perlin_turb(const float *ranvec, const int *perm, f3 p) {
     for (int i = 0; i < 7; i++) { accum += weight * perlin_noise(ranvec, perm, p); weight *= 0.5f; p = p * 2.0f; }
     return fabsf(accum);
 }
+// NOISE = false: for scenes without a perlin texture (SceneT::tex_kinds) -- the turbulence loop is what sets the register
+// count of the shading kernels
+template <bool NOISE = true>
 RT_DEV f3 texture_value(const SceneT<float> &sc, int tex, float u, float v, f3 p) {
     TextureT<float> t = sc.textures[tex];
     for (int guard = 0; guard < 8 && t.type == RTC_TEX_CHECKER; ++guard) {           // texture.c:121-124
@@ -103,7 +106,7 @@ RT_DEV f3 texture_value(const SceneT<float> &sc, int tex, float u, float v, f3 p
         t = sc.textures[sines < 0 ? t.a : t.b];
     }
     if (t.type == RTC_TEX_SOLID) return f3mk(t.v[0], t.v[1], t.v[2]);
-    if (t.type == RTC_TEX_NOISE) {                                                    // texture.c:128-132
+    if (NOISE && t.type == RTC_TEX_NOISE) {                                           // texture.c:128-132
         const float perl = perlin_turb(sc.perlin_vec + 768 * t.a, sc.perlin_perm + 768 * t.a, p);
         const float val = 0.5f * (1.0f + sinf(t.v[0] * p.z + 10 * perl));
         return f3mk(val, val, val);
@@ -265,12 +268,13 @@ RT_DEV f3 dielectric_dir(float ir, f3 dir, const RecT<float> &rec, float xi) {  
 
 // Shade one hit.  integrator 0: ray.c:58-83 in loop form (L += T*emitted; T *= att*scattering_pdf/pdf_val).
 // integrator 1/2: 02 main.c:54-62 / 01 main.c:45-56 (T *= attenuation).  xi = this bounce's Philox block.
+template <bool NOISE = true>
 RT_DEV int shade_hit(const SceneT<float> &sc, PathState &ps, const RecT<float> &rec, int integrator, float light_weight, const Rng4 &xi) {
     const MaterialT<float> m = sc.materials[rec.mat];
     const f3 d = ps.ray.d;
     RayT<float> next; next.o = rec.p; next.time = ps.ray.time;
     if (m.type == RTC_MAT_LIGHT) {                                                     // material.c:229-235 (03: front face only, F15)
-        if (integrator != 2 && (integrator == 1 || rec.front)) ps.L = ps.L + ps.T * texture_value(sc, m.tex, rec.u, rec.v, rec.p);
+        if (integrator != 2 && (integrator == 1 || rec.front)) ps.L = ps.L + ps.T * texture_value<NOISE>(sc, m.tex, rec.u, rec.v, rec.p);
         return RT_TERMINATE;                                                           // material_light_scatter returns 0
     }
     if (m.type == RTC_MAT_METAL) {                                                     // material.c:130-138 / 02 :132-141
@@ -287,11 +291,11 @@ RT_DEV int shade_hit(const SceneT<float> &sc, PathState &ps, const RecT<float> &
     if (m.type == RTC_MAT_ISOTROPIC) {                                                 // 02 material.c:173-177; 03's is UB (F14) -> absorb
         if (integrator == 0) return RT_TERMINATE;
         next.d = uniform_ball(xi.x, xi.y, xi.z);
-        ps.T = ps.T * texture_value(sc, m.tex, rec.u, rec.v, rec.p);
+        ps.T = ps.T * texture_value<NOISE>(sc, m.tex, rec.u, rec.v, rec.p);
         ps.ray = next; return RT_CONTINUE;
     }
     // lambertian
-    const f3 att = texture_value(sc, m.tex, rec.u, rec.v, rec.p);
+    const f3 att = texture_value<NOISE>(sc, m.tex, rec.u, rec.v, rec.p);
     if (integrator != 0) {                                                             // 02 material.c:120-128
         f3 dir = rec.n + uniform_sphere(xi.x, xi.y);
         if (fabsf(dir.x) < 1e-8f && fabsf(dir.y) < 1e-8f && fabsf(dir.z) < 1e-8f) dir = rec.n;

@@ -152,7 +152,8 @@ constexpr int kWfShadeBlock = RT_WF_SHADE_BLOCK;
 #ifndef RT_WF_SHADE_WAVES
 #define RT_WF_SHADE_WAVES 5
 #endif
-__global__ void __launch_bounds__(kWfShadeBlock) __attribute__((amdgpu_waves_per_eu(RT_WF_SHADE_WAVES))) k_wf_shade(SceneT<float> sc, CameraT<float> cam, RenderParams P, WfBuffers B, int cur, unsigned n_list) {
+template <bool NOISE>
+__global__ void __launch_bounds__(kWfShadeBlock) __attribute__((amdgpu_waves_per_eu(NOISE ? RT_WF_SHADE_WAVES : 6))) k_wf_shade(SceneT<float> sc, CameraT<float> cam, RenderParams P, WfBuffers B, int cur, unsigned n_list) {
     __shared__ unsigned key_count[32], key_start[32];
     __shared__ int sorted_slot[kWfShadeBlock];
     __shared__ unsigned sorted_index[kWfShadeBlock];
@@ -196,7 +197,7 @@ __global__ void __launch_bounds__(kWfShadeBlock) __attribute__((amdgpu_waves_per
             const MaterialT<float> &mat = sc.materials[p.mat];
             const RecT<float> rec = resolve_hit<float>(sc, ps.ray, p, hh.x, material_needs_uv(sc, mat));
             const Rng4 xi = rng_block(pixel, (uint32_t)m.x, (uint32_t)m.y, P.seed_lo, P.seed_hi);
-            status = shade_hit(sc, ps, rec, P.integrator, P.light_weight, xi);
+            status = shade_hit<NOISE>(sc, ps, rec, P.integrator, P.light_weight, xi);
             m.z = p.type == RTC_PRIM_MEDIUM ? -1 : hslot;
         }
         ++m.y;
@@ -277,7 +278,9 @@ hipError_t launch_wf_bounce(const SceneT<float> &sc, const CameraT<float> &cam, 
     else if (sc.media_kind == 0) hipLaunchKernelGGL((k_wf_extend<0, RTC_KIND_ALL>), dim3(blocks), dim3(kWfExtendBlock), lds, stream, sc, p, b, cur, n_list);
     else if (sc.media_kind == 1) hipLaunchKernelGGL((k_wf_extend<1, RTC_KIND_ALL>), dim3(blocks), dim3(kWfExtendBlock), lds, stream, sc, p, b, cur, n_list);
     else hipLaunchKernelGGL((k_wf_extend<2, RTC_KIND_ALL>), dim3(blocks), dim3(kWfExtendBlock), lds, stream, sc, p, b, cur, n_list);
-    hipLaunchKernelGGL(k_wf_shade, dim3((n_list + kWfShadeBlock - 1) / kWfShadeBlock), dim3(kWfShadeBlock), 0, stream, sc, cam, p, b, cur, n_list);
+    const dim3 sgrid((n_list + kWfShadeBlock - 1) / kWfShadeBlock);
+    if (sc.tex_kinds & (1 << RTC_TEX_NOISE)) hipLaunchKernelGGL(k_wf_shade<true>, sgrid, dim3(kWfShadeBlock), 0, stream, sc, cam, p, b, cur, n_list);
+    else hipLaunchKernelGGL(k_wf_shade<false>, sgrid, dim3(kWfShadeBlock), 0, stream, sc, cam, p, b, cur, n_list);
     return hipGetLastError();
 }
 hipError_t launch_wf_compact(const WfBuffers &b, int cur, unsigned n_list, hipStream_t stream) {

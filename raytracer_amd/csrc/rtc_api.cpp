@@ -82,6 +82,7 @@ template <typename R> hipError_t upload_tables(const FlatScene &fs, DeviceTables
     v.bvh_depth = fs.bvh_depth < 1 ? 1 : (fs.bvh_depth > RTC_BVH_MAX_DEPTH ? RTC_BVH_MAX_DEPTH : fs.bvh_depth);
     v.n_media = fs.n_media;
     v.leaf_kinds = fs.leaf_kinds;
+    v.tex_kinds = 0; for (const auto &t : fs.textures) v.tex_kinds |= 1 << t.type;
     v.media_kind = fs.n_media ? (fs.nodes.empty() ? 2 : fs.media_kind) : 0;
     for (int i = 0; i < 3; i++) v.background[i] = (R)fs.background[i];
     dt.ready = true;

@@ -82,6 +82,7 @@ template <typename R> struct SceneT {
     const RefStep *ref_steps; const double *ref_boxes; int n_ref_steps;   // FP64 check path; boxes = min xyz, max xyz
     int n_media;             // media among prims (stochastic hits)
     int leaf_kinds;          // BVH leaves: bit 0 rects, bit 1 spheres, bit 2 moving spheres, bit 3 boxes (RTC_KIND_*, rt_core.hpp)
+    int tex_kinds;           // texture types in the scene: bit RTC_TEX_*
     int media_kind;          // BVH leaves: 0 no media, 1 sphere-bounded media only (BLeaf carries them), 2 general boundaries
     R background[3];
 };

@@ -43,9 +43,10 @@ PEAK_FP32_VALU_TFLOPS = 157.3     # MI355X_MICROARCH.md: 256 CU x 4 SIMD x 32 la
 ALGO_HBM_BYTES_PER_PIXEL = 32     # float4 accumulator read + write once per launch
 PEAK_L2_GBS = 34500.0             # MI355X_MICROARCH.md: 8 x 4 MiB L2, ~34.5 TB/s aggregate (HBM3E: 8 TB/s)
 # BVH scenes (wavefront kernels): measured traversal steps per ray (probe builds RT_EXP=3/4) ->
-# algorithmic bytes per ray = node steps x 64 B + leaf steps x 36 B (32-B leaf + its primitive id) + 232 B of path-slot state
-SCENE_BYTES = {"final": 13.0 * 64 + 4.8 * 36 + 232, "final_earth": 13.0 * 64 + 4.8 * 36 + 232, "book1": 8.7 * 64 + 3.8 * 36 + 232,
-               "million": 22.7 * 64 + 4.4 * 36 + 232}
+# algorithmic bytes per ray = (node steps + leaf steps) x 64 B (node and traversal leaf are both 64 B; steps measured with
+# the RT_EXP=3/4 probe builds) + 166 B of path-slot state per bounce (extend 48 R + 9 W, shade 61 R + 48 W)
+SCENE_BYTES = {"final": (9.4 + 5.5) * 64 + 166, "final_earth": (9.1 + 4.8) * 64 + 166, "book1": (8.7 + 3.8) * 64 + 166,
+               "million": (22.7 + 4.3) * 64 + 166}
 
 
 def measured_traffic():

@@ -196,26 +196,34 @@ template <bool GENERAL> struct MediumSamplerT {
 using MediumSampler = MediumSamplerT<true>;
 
 // ---- light list pdf / sampling (hittable_list.c:165-180, hittable.c:760-864) -------------------------
+// The light record is wave-uniform (the callers loop over the list), so kind and axis are scalar branches; below them
+// there are no early returns -- the hit tests of rect_t / sphere_t are folded into one select each.
 RT_DEV float light_pdf_one(const LightT<float> &l, f3 o, f3 v) {
     if (l.kind == RTC_LIGHT_RECT) {                                                   // :772-788, tmin 1e-4
-        RayT<float> r; r.o = o; r.d = v; r.time = 0;
-        float t;
-        if (!rect_t<float>(l.d, l.axis, r, 0.0001f, Mth<float>::inf(), t)) return 0.0f;
+        const bool xy = l.axis == RTC_AXIS_XY, xz = l.axis == RTC_AXIS_XZ, yz = l.axis == RTC_AXIS_YZ;
+        const float on = xy ? o.z : (xz ? o.y : o.x), vn = xy ? v.z : (xz ? v.y : v.x);
+        const float oa = yz ? o.y : o.x, va = yz ? v.y : v.x, ob = xy ? o.y : o.z, vb = xy ? v.y : v.z;
+        const float a0 = yz ? l.d[2] : l.d[0], a1 = yz ? l.d[3] : l.d[1], b0 = xy ? l.d[2] : l.d[4], b1 = xy ? l.d[3] : l.d[5];
+        const float t = (l.d[6] - on) * __builtin_amdgcn_rcpf(vn);                    // rect_hit :494-517
+        const float pa = oa + t * va, pb = ob + t * vb;
+        const bool hit = !(t < 0.0001f) & !(pa < a0) & !(pa > a1) & !(pb < b0) & !(pb > b1);   // a NaN t passes (F20)
         const float vv = len2(v);
         const float distance_squared = t * t * vv;
-        const float area = l.axis == RTC_AXIS_XZ ? (l.d[1] - l.d[0]) * (l.d[5] - l.d[4])
-                         : l.axis == RTC_AXIS_XY ? (l.d[1] - l.d[0]) * (l.d[3] - l.d[2]) : (l.d[3] - l.d[2]) * (l.d[5] - l.d[4]);
-        const float vn = l.axis == RTC_AXIS_XZ ? v.y : (l.axis == RTC_AXIS_XY ? v.z : v.x);
+        const float area = (a1 - a0) * (b1 - b0);
         const float cosine = fabsf(vn) * __builtin_amdgcn_rsqf(vv);
-        return distance_squared * __builtin_amdgcn_rcpf(cosine * area);
+        return hit ? distance_squared * __builtin_amdgcn_rcpf(cosine * area) : 0.0f;
     }
     if (l.kind == RTC_LIGHT_SPHERE) {                                                 // :760-768, tmin 1e-3
-        RayT<float> r; r.o = o; r.d = v; r.time = 0;
         const f3 c = f3mk(l.d[0], l.d[1], l.d[2]);
-        float t;
-        if (!sphere_t<float>(c, l.d[3], r, 0.001f, Mth<float>::inf(), t)) return 0.0f;
-        const float cos_theta_max = __builtin_amdgcn_sqrtf(1.0f - l.d[3] * l.d[3] * __builtin_amdgcn_rcpf(len2(c - o)));
-        return __builtin_amdgcn_rcpf(2.0f * RT_PI * (1.0f - cos_theta_max));
+        const f3 oc = o - c;
+        const float inv_a = __builtin_amdgcn_rcpf(len2(v));                           // closest-approach form, rt_core.hpp sphere_t<float>
+        const float tc = -dot(oc, v) * inv_a;
+        const f3 lv = oc + v * tc;
+        const float q = (l.d[3] * l.d[3] - len2(lv)) * inv_a;
+        const float sq = __builtin_amdgcn_sqrtf(fmaxf(q, 0.0f));
+        const bool hit = !(q < 0.0f) & (!(tc - sq < 0.001f) | !(tc + sq < 0.001f));    // NaN passes as in sphere_t
+        const float cos_theta_max = __builtin_amdgcn_sqrtf(1.0f - l.d[3] * l.d[3] * __builtin_amdgcn_rcpf(len2(oc)));
+        return hit ? __builtin_amdgcn_rcpf(2.0f * RT_PI * (1.0f - cos_theta_max)) : 0.0f;
     }
     return 0.0f;
 }

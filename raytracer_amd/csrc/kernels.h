@@ -45,6 +45,7 @@ struct WfBuffers {
     unsigned *counters;               // 16 words: [0] live slots, [1] compaction cursor
     unsigned long long *stats;        // wf_stats_bytes(): [0] rays, [1] extend waves; 16 striped partial counters behind
     int n_slots, slots_per_layer, layers;
+    int quad;                         // slot <-> (pixel, layer) mapping of kernels_wf.hip slot_pixel
 };
 size_t wf_bytes_per_slot();
 size_t wf_stats_bytes();

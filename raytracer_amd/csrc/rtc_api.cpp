@@ -332,6 +332,8 @@ static int render_wavefront(rtc_scene *s, const CameraT<float> &camf, const Rend
     b.stats = (unsigned long long *)s->ray_counter.p;
     b.counters = (unsigned *)((char *)s->ray_counter.p + wf_stats_bytes());
     b.n_slots = (int)n_slots; b.slots_per_layer = (int)per_layer; b.layers = (int)layers;
+    b.quad = layers % 4 == 0;
+    if (const char *e = std::getenv("RTC_WF_QUAD")) b.quad = b.quad && std::atoi(e) != 0;   // A/B knob
     HIP_TRY(launch_wf_init(camf, p, b, stream));
     const long long max_iterations = ((spp + layers - 1) / layers) * (long long)(p.max_depth > 0 ? p.max_depth : 1) + 1;
     unsigned n_list = (unsigned)n_slots;

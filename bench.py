@@ -189,7 +189,7 @@ def main():
             "mrays_per_s": rays_all / elapsed / 1e6, "rays_per_sample": rays_all / samples_all,
             "roofline": {"bound": "valu", "achieved": achieved, "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP32_VALU_TFLOPS, "traffic": traffic["bytes"] if traffic else None,
-                         "traffic_source": traffic, "kernel": "k_pathtrace_small<0, false>" if kernel_used[0] == 2 else "k_pathtrace_mega",
+                         "traffic_source": traffic, "kernel": "k_pathtrace_small<0, false, false>" if kernel_used[0] == 2 else "k_pathtrace_mega",
                          "lane_fill": lane_fill[0], "kernel_ms": k_ms, "rays_per_launch": rays_per_launch,
                          "algorithmic_flop_per_ray": ALGO_FLOP_PER_RAY,
                          "algorithmic_hbm_bytes_per_launch": ALGO_HBM_BYTES_PER_PIXEL * WIDTH * HEIGHT},

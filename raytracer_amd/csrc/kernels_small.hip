@@ -160,7 +160,8 @@ RT_DEV f3 small_light_sample(const SceneT<float> &sc, int pick, f3 o, float r1, 
 
 // PROBE = true: the one-sample cost probe of launch_pathtrace_small (its own kernel name in profiles): writes the rays of
 // each tile to tile_cost and nothing else.
-template <int INTEGRATOR, bool PROBE>
+// LENS = false: pinhole camera (aperture 0, every reference scene but Book 1 / Book 2 random): no lens sample in the loop.
+template <int INTEGRATOR, bool LENS, bool PROBE>
 __global__ void __launch_bounds__(256) k_pathtrace_small(SmallScene ss, SceneT<float> sc, CameraT<float> cam, RenderParams P,
                                                           float4 *__restrict__ accum, unsigned long long *__restrict__ counters,
                                                           const int *__restrict__ tile_perm, int *__restrict__ tile_cost,
@@ -200,7 +201,7 @@ __global__ void __launch_bounds__(256) k_pathtrace_small(SmallScene ss, SceneT<f
             const Rng4 c = rng_block(pixel, s_cur, RT_TAG_CAMERA, P.seed_lo, P.seed_hi);
             const float u = ((float)px + c.x) * inv_w, v = ((float)py + c.y) * inv_h;
             float dx = 0.0f, dy = 0.0f;
-            if (cam.lens_radius > 0.0f) { const float rr = __builtin_amdgcn_sqrtf(c.z); dx = rr * cos2pi(c.w); dy = rr * sin2pi(c.w); }
+            if (LENS) { const float rr = __builtin_amdgcn_sqrtf(c.z); dx = rr * cos2pi(c.w); dy = rr * sin2pi(c.w); }
             const RayT<float> r = camera_ray<float>(cam, u, v, dx, dy, 0.0f);   // no leaf moves: the ray time is never read
             ro = r.o; rd = r.d;
             T = f3mk(1, 1, 1); L = f3mk(0, 0, 0);
@@ -322,9 +323,12 @@ template <bool PROBE>
 static void launch_small(const SmallScene &ss, const SceneT<float> &sc, const CameraT<float> &cam, const RenderParams &p, float4 *accum,
                          unsigned long long *counters, const int *perm, int *cost, float4 *partial, int log2_chunks, hipStream_t stream) {
     const unsigned blocks = (unsigned)((((long long)p.n_tiles << log2_chunks) + 3) / 4);
-    if (p.integrator == 0) hipLaunchKernelGGL((k_pathtrace_small<0, PROBE>), dim3(blocks), dim3(256), 0, stream, ss, sc, cam, p, accum, counters, perm, cost, partial, log2_chunks);
-    else if (p.integrator == 1) hipLaunchKernelGGL((k_pathtrace_small<1, PROBE>), dim3(blocks), dim3(256), 0, stream, ss, sc, cam, p, accum, counters, perm, cost, partial, log2_chunks);
-    else hipLaunchKernelGGL((k_pathtrace_small<2, PROBE>), dim3(blocks), dim3(256), 0, stream, ss, sc, cam, p, accum, counters, perm, cost, partial, log2_chunks);
+#define RT_SMALL_LAUNCH(I, L) hipLaunchKernelGGL((k_pathtrace_small<I, L, PROBE>), dim3(blocks), dim3(256), 0, stream, ss, sc, cam, p, accum, counters, perm, cost, partial, log2_chunks)
+    const bool lens = cam.lens_radius > 0.0f;
+    if (p.integrator == 0) { if (lens) RT_SMALL_LAUNCH(0, true); else RT_SMALL_LAUNCH(0, false); }
+    else if (p.integrator == 1) { if (lens) RT_SMALL_LAUNCH(1, true); else RT_SMALL_LAUNCH(1, false); }
+    else { if (lens) RT_SMALL_LAUNCH(2, true); else RT_SMALL_LAUNCH(2, false); }
+#undef RT_SMALL_LAUNCH
 }
 
 // tile_scratch: 2 * n_tiles ints (cost, order) or NULL.  A wave owns a tile for its samples of the launch, and an interior

@@ -162,7 +162,7 @@ RT_DEV f3 small_light_sample(const SceneT<float> &sc, int pick, f3 o, float r1, 
 // each tile to tile_cost and nothing else.
 // LENS = false: pinhole camera (aperture 0, every reference scene but Book 1 / Book 2 random): no lens sample in the loop.
 template <int INTEGRATOR, bool LENS, bool PROBE>
-__global__ void __launch_bounds__(256) k_pathtrace_small(SmallScene ss, SceneT<float> sc, CameraT<float> cam, RenderParams P,
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) k_pathtrace_small(SmallScene ss, SceneT<float> sc, CameraT<float> cam, RenderParams P,
                                                           float4 *__restrict__ accum, unsigned long long *__restrict__ counters,
                                                           const int *__restrict__ tile_perm, int *__restrict__ tile_cost,
                                                           float4 *__restrict__ partial, int log2_chunks) {
@@ -193,17 +193,33 @@ __global__ void __launch_bounds__(256) k_pathtrace_small(SmallScene ss, SceneT<f
     int s_next = s_lo, depth = 0, src = -1;
     uint32_t s_cur = 0;
     bool alive = false;
+    // Primary rays are generated ahead, two per lane (b0 is used first): a third of the lanes ends a path in every
+    // iteration, so generating on demand runs the camera code (a Philox block and the ray set-up) in EVERY iteration
+    // for a third of the wave; filled only when some lane has run dry, it runs every few iterations for most of it
+    // (a third buffered ray changes nothing).  6 waves/SIMD = 80 VGPRs without spills: 24.6 ms at 5 waves, 23.3 at 6, 23.6
+    // at 7 (5 spilled), 24.9 at 8 (15 spilled).
+    f3 b0d = rd, b1d = rd, b0o = ro, b1o = ro;
+    int n_buf = 0;                                                        // buffered samples: s_next - n_buf .. s_next - 1
+    auto primary = [&](uint32_t s, f3 &o, f3 &d) {                        // main.c:150-152 + camera.c:46-53
+        const Rng4 c = rng_block(pixel, s, RT_TAG_CAMERA, P.seed_lo, P.seed_hi);
+        const float u = ((float)px + c.x) * inv_w, v = ((float)py + c.y) * inv_h;
+        float dx = 0.0f, dy = 0.0f;
+        if (LENS) { const float rr = __builtin_amdgcn_sqrtf(c.z); dx = rr * cos2pi(c.w); dy = rr * sin2pi(c.w); }
+        const RayT<float> r = camera_ray<float>(cam, u, v, dx, dy, 0.0f);   // no leaf moves: the ray time is never read
+        o = r.o; d = r.d;
+    };
 
     for (;;) {
         if (P.max_depth <= 0) break;                                       // ray.c:52
-        if (!alive && valid && s_next < s_hi) {                            // main.c:150-152 + camera.c:46-53
-            s_cur = (uint32_t)s_next++;
-            const Rng4 c = rng_block(pixel, s_cur, RT_TAG_CAMERA, P.seed_lo, P.seed_hi);
-            const float u = ((float)px + c.x) * inv_w, v = ((float)py + c.y) * inv_h;
-            float dx = 0.0f, dy = 0.0f;
-            if (LENS) { const float rr = __builtin_amdgcn_sqrtf(c.z); dx = rr * cos2pi(c.w); dy = rr * sin2pi(c.w); }
-            const RayT<float> r = camera_ray<float>(cam, u, v, dx, dy, 0.0f);   // no leaf moves: the ray time is never read
-            ro = r.o; rd = r.d;
+        const bool starving = !alive && valid && n_buf == 0 && s_next < s_hi;
+        if (__builtin_amdgcn_ballot_w64(starving) != 0) {
+            if (valid && n_buf == 0 && s_next < s_hi) { primary((uint32_t)s_next++, b0o, b0d); n_buf = 1; }
+            if (valid && n_buf == 1 && s_next < s_hi) { primary((uint32_t)s_next++, b1o, b1d); n_buf = 2; }
+        }
+        if (!alive && n_buf > 0) {
+            s_cur = (uint32_t)(s_next - n_buf); --n_buf;
+            rd = b0d; b0d = b1d;
+            if (LENS) { ro = b0o; b0o = b1o; } else ro = f3mk(cam.origin[0], cam.origin[1], cam.origin[2]);
             T = f3mk(1, 1, 1); L = f3mk(0, 0, 0);
             depth = 0; alive = true; src = -1;
         }

@@ -122,7 +122,7 @@ enum { RT_SCENE_SIMPLE = 0, RT_SCENE_CORNELL = 1, RT_SCENE_FINAL = 2, RT_SCENE_B
        RT_SCENE_CORNELL02 = 4, RT_SCENE_CORNELL_SMOKE = 5, RT_SCENE_TWO_SPHERES = 6,
        RT_SCENE_TWO_PERLIN = 7, RT_SCENE_SIMPLE_LIGHT = 8, RT_SCENE_BOOK2_RANDOM = 9,
        RT_SCENE_MILLION = 10, RT_SCENE_EARTH = 11, RT_SCENE_FINAL_EARTH = 12,
-       RT_SCENE_BOX_FIELD = 13 /* not a reference scene: rotated boxes inside a BVH (host/scenes.c) */ };
+       RT_SCENE_BOX_FIELD = 13, RT_SCENE_BOX_FIELD_SMOKE = 14 /* not reference scenes: rotated boxes (and media) inside a BVH (host/scenes.c) */ };
 #define RT_SCENES_TYPES 1
 hittable_list *rt_scene_build(int id, int arg, hittable_list *lights, rt_scene_view *view);
 /* image file of RT_SCENE_EARTH / RT_SCENE_FINAL_EARTH (the reference hard-codes "images/earthmap.jpg", 02 main.c:159);

@@ -35,7 +35,7 @@ typedef struct rt_scene_view {
 enum { RT_SCENE_SIMPLE = 0, RT_SCENE_CORNELL = 1, RT_SCENE_FINAL = 2, RT_SCENE_BOOK1 = 3,
        RT_SCENE_CORNELL02 = 4, RT_SCENE_CORNELL_SMOKE = 5, RT_SCENE_TWO_SPHERES = 6,
        RT_SCENE_TWO_PERLIN = 7, RT_SCENE_SIMPLE_LIGHT = 8, RT_SCENE_BOOK2_RANDOM = 9,
-       RT_SCENE_MILLION = 10, RT_SCENE_EARTH = 11, RT_SCENE_FINAL_EARTH = 12, RT_SCENE_BOX_FIELD = 13 };
+       RT_SCENE_MILLION = 10, RT_SCENE_EARTH = 11, RT_SCENE_FINAL_EARTH = 12, RT_SCENE_BOX_FIELD = 13, RT_SCENE_BOX_FIELD_SMOKE = 14 };
 #endif
 
 static vec3 sv3(double x, double y, double z) { vec3 v; v.x = x; v.y = y; v.z = z; return v; }
@@ -206,8 +206,9 @@ static hittable_list *scene_cornell02(int smoke, rt_scene_view *v) {
 
 /* Not a scene of the reference: the 02 Cornell room (main.c:186-199) filled with 18 boxes under rotate_x / rotate_y /
  * rotate_z + translate and 8 spheres.  114 leaves, so it is flattened into a BVH whose rect leaves are ROTATED -- the
- * case none of the reference's own scenes puts into a BVH.  Deterministic (no rand()). */
-static hittable_list *scene_box_field(rt_scene_view *v) {
+ * case none of the reference's own scenes puts into a BVH.  Deterministic (no rand()).  smoke: plus two constant media
+ * (02 main.c:217-224 style), one bounded by a rotated box, so that a BVH scene carries a general medium. */
+static hittable_list *scene_box_field(rt_scene_view *v, int smoke) {
     hittable_list *world = hittable_list_new(1024);
     material *red = material_lambertian_new_from_color(sv3(0.65, 0.05, 0.05));
     material *white = material_lambertian_new_from_color(sv3(0.73, 0.73, 0.73));
@@ -230,6 +231,14 @@ static hittable_list *scene_box_field(rt_scene_view *v) {
     }
     for (int i = 0; i < 8; i++)
         hittable_sphere_new(world, sv3(70 + 60 * i, 330 + 25 * (i % 3), 200 + 35 * ((i * 3) % 5)), 22 + 3 * (i % 4), i % 2 ? glass : steel);
+    if (smoke) {   /* a box-bounded medium (general boundary: two list queries per visit) and a sphere-bounded one, inside the BVH */
+        hittable *b = hittable_box_new(NULL, sv3(0, 0, 0), sv3(150, 200, 150), white);
+        b = hittable_rotate_init(NULL, b, 20, Y);
+        b = hittable_translate_init(NULL, b, sv3(200, 150, 250));
+        hittable_constant_medium_init_c(world, b, 0.008, sv3(0.1, 0.1, 0.1));
+        hittable *ball = hittable_sphere_new(NULL, sv3(400, 300, 150), 90, white);
+        hittable_constant_medium_init_c(world, ball, 0.01, sv3(0.9, 0.9, 1.0));
+    }
     view_cornell(v); v->integrator = 1; v->max_depth = 8;
     return world;
 }
@@ -353,7 +362,8 @@ hittable_list *rt_scene_build(int id, int arg, hittable_list *lights, rt_scene_v
     case RT_SCENE_SIMPLE_LIGHT: return scene_perlin(1, view);
     case RT_SCENE_BOOK2_RANDOM: return scene_book2_random(view);
     case RT_SCENE_MILLION: return scene_million(arg > 0 ? arg : 1000, view);
-    case RT_SCENE_BOX_FIELD: return scene_box_field(view);
+    case RT_SCENE_BOX_FIELD: return scene_box_field(view, 0);
+    case RT_SCENE_BOX_FIELD_SMOKE: return scene_box_field(view, 1);
     default: return NULL;
     }
 }

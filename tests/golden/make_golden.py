@@ -60,7 +60,7 @@ FIRST_HIT = (("simple", 3, "ref_simple"), ("cornell", 3, "ref_cornell"), ("corne
              ("cornell02_scenes_c", 2, "cornell02"), ("cornell_smoke", 2, "cornell_smoke"), ("book2_random", 2, "book2_random"),
              ("two_perlin", 2, "two_perlin"), ("simple_light", 2, "simple_light"), ("two_spheres", 2, "two_spheres"),
              ("earth", 2, "earth"), ("final_earth", 2, "final_earth"),
-             ("box_field", 2, "box_field"))   # image texture: tests/golden/earthmap_512.ppm (make_earth_fixture.py)
+             ("box_field", 2, "box_field"), ("box_field_smoke", 2, "box_field_smoke"))   # image texture: tests/golden/earthmap_512.ppm (make_earth_fixture.py)
 
 
 def task_first_hit(name):

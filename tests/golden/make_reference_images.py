@@ -31,6 +31,7 @@ JOBS = [  # name, stage, scene, aspect, W, H, spp
     ("earth_128", 2, "earth", 0.0, 128, 72, 512),
     ("final_earth_96", 2, "final_earth", 0.0, 96, 96, 1024),
     ("box_field_96", 2, "box_field", 0.0, 96, 96, 2048),          # not a reference scene: rotated rects inside a BVH
+    ("box_field_smoke_96", 2, "box_field_smoke", 0.0, 96, 96, 2048),   # ... plus a box-bounded and a sphere-bounded medium
 ]
 
 

@@ -18,7 +18,7 @@ REF02_SO = os.path.join(ROOT, "oracle", "_ref", "libref02.so")
 EARTHMAP = os.path.join(ROOT, "tests", "golden", "earthmap_512.ppm")   # image asset of the earth scenes (make_earth_fixture.py)
 
 SCENE = dict(simple=0, cornell=1, final=2, book1=3, cornell02=4, cornell_smoke=5, two_spheres=6,
-             two_perlin=7, simple_light=8, book2_random=9, million=10, earth=11, final_earth=12, box_field=13,
+             two_perlin=7, simple_light=8, book2_random=9, million=10, earth=11, final_earth=12, box_field=13, box_field_smoke=14,
              ref_simple=-1, ref_cornell=-2, ref_final=-8, ref_cornell02=-6)
 MAT = dict(lambertian=0, metal=1, dielectric=2, light=3, isotropic=4)
 

@@ -24,6 +24,7 @@ FIXTURES = {
     "two_perlin": ("two_perlin", None, 2), "simple_light": ("simple_light", None, 2), "two_spheres": ("two_spheres", None, 2),
     "earth": ("earth", None, 2), "final_earth": ("final_earth", None, 2),
     "box_field": ("box_field", None, 2),                         # not a reference scene: rotated rects inside a BVH
+    "box_field_smoke": ("box_field_smoke", None, 2),             # ... plus a box-bounded and a sphere-bounded medium
 }
 EXACT_COLS = [0, 1, 2, 3, 4, 5, 6, 7, 10, 11]   # hit, t, p, normal, front_face, material type
 

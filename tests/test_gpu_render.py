@@ -38,6 +38,9 @@ TOL = {
     # not a reference scene: rotated rects in a BVH.  Bright lamp, no light sampling in 02: the fixture's own noise at
     # 2048 spp is RMSE 0.034 (a 2048-spp GPU render against a 32768-spp one: 0.0341); measured against it 0.0338 / 0.0088
     "box_field_96":      ("box_field",     None,   (0.0400, 0.0105, 0.010)),
+    # the same room with a box-bounded (general boundary) and a sphere-bounded medium: the only BVH scene with a general
+    # medium, i.e. the only one that runs k_wf_extend<2, ...>
+    "box_field_smoke_96": ("box_field_smoke", None, (0.0400, 0.0105, 0.010)),
 }
 LUMA = np.array([0.2126, 0.7152, 0.0722])
 
@@ -240,7 +243,7 @@ def test_small_scene_kernel_refuses_ineligible_scenes(gpu):
         sc.close()
 
 
-@pytest.mark.parametrize("name,blk_tol", [("book1", 0.0005), ("final", 0.001), ("book2_random", 0.0005)])
+@pytest.mark.parametrize("name,blk_tol", [("book1", 0.0005), ("final", 0.001), ("book2_random", 0.0005), ("box_field_smoke", 0.001)])
 def test_wavefront_kernel_agrees_with_megakernel(gpu, name, blk_tol):
     """kernel=3 (wavefront: extend / shade stages over path slots in HBM) and kernel=1 (persistent megakernel) run the same
     estimator with the same Philox keys (pixel, sample, bounce); the FP32 sums differ only by the order of the additions

@@ -17,6 +17,7 @@ FIRST_HIT = {
     "cornell02": (2, "cornell02", 0), "cornell02_scenes_c": (2, "cornell02", 0), "cornell_smoke": (2, "cornell_smoke", 0),
     "book2_random": (2, "book2_random", 0), "two_perlin": (2, "two_perlin", 0), "simple_light": (2, "simple_light", 0), "two_spheres": (2, "two_spheres", 0),
     "earth": (2, "earth", 0), "final_earth": (2, "final_earth", 0), "box_field": (2, "box_field", 0),
+    "box_field_smoke": (2, "box_field_smoke", 0),
 }
 
 

@@ -398,3 +398,23 @@ def test_library_facade_make_render_free(gpu, tmp_path):
     finally:
         L.free_scene(s)
         sc.close()
+
+
+def test_full_size_4k_shards_add_up(gpu):
+    """BASELINE config 4 at its image size (3840x2160, the 8-GPU run): two GPUs' sample shards, rendered one after the other
+    here, add up to the one-call render of the union (same Philox counters; FP32 sums reassociated -> 1e-5 relative), the
+    sample counts are exact, and the render is deterministic.  8 spp instead of 16,384: the property does not depend on it."""
+    sc, cam, view = gpu.build_named_scene("cornell", aspect=16 / 9)
+    try:
+        W, H = 3840, 2160
+        full, st = sc.render(cam, gpu.Settings(W, H, 8, 10, 0, seed=4))
+        assert st["kernel_used"] == 2 and st["samples"] == W * H * 8
+        again, _ = sc.render(cam, gpu.Settings(W, H, 8, 10, 0, seed=4))
+        assert np.array_equal(full, again)
+        acc = np.zeros((H, W, 4), dtype=np.float32)
+        for b, e in ((0, 4), (4, 8)):
+            acc, _ = sc.render(cam, gpu.Settings(W, H, 0, 10, 0, seed=4, sample_begin=b, sample_end=e), accum=acc)
+        assert (acc[..., 3] == 8).all()
+        assert np.allclose(acc[..., :3], full[..., :3], rtol=1e-5, atol=1e-6)
+    finally:
+        sc.close()

@@ -26,9 +26,10 @@ hipError_t launch_pathtrace_mega(const SceneT<float> &sc, const CameraT<float> &
                                  float4 *accum, unsigned long long *ray_counter, hipStream_t stream);
 // Small-scene persistent path tracer (kernels_small.hip): counters[0] += rays, counters[1] += wave bounce-iterations.
 // tile_scratch: 2 * p.n_tiles ints of device memory for the heaviest-first tile order, or NULL (tiles in image order).
+// *ordered: in = tile_scratch already holds the order for this camera and image (skip the probe); out = it holds one now.
 // partial: 2^log2_chunks planes of W*H float4 when a tile's samples are split over 2^log2_chunks waves, or NULL.
 hipError_t launch_pathtrace_small(const SmallScene &ss, const SceneT<float> &sc, const CameraT<float> &cam, const RenderParams &p,
-                                  float4 *accum, unsigned long long *counters, int *tile_scratch, float4 *partial, int log2_chunks, hipStream_t stream);
+                                  float4 *accum, unsigned long long *counters, int *tile_scratch, int *ordered, float4 *partial, int log2_chunks, hipStream_t stream);
 // Production FP32 traversal alone (brute-force loop or flattened BVH), one lane per ray; media skipped.
 hipError_t launch_first_hit_f32(const SceneT<float> &sc, const float *rays7, size_t n, float tmin, float tmax, int32_t *prim_id, float *t, hipStream_t stream);
 hipError_t launch_tonemap_u8(const float4 *accum, int n_pixels, unsigned char *rgb, hipStream_t stream);

@@ -355,17 +355,21 @@ static void launch_small(const SmallScene &ss, const SceneT<float> &sc, const Ca
 //    sums go to their own plane and are added in a fixed order afterwards -- four times finer work items for 0.1 ms of
 //    extra HBM traffic, and still no atomics on radiance.
 hipError_t launch_pathtrace_small(const SmallScene &ss, const SceneT<float> &sc, const CameraT<float> &cam, const RenderParams &p,
-                                  float4 *accum, unsigned long long *counters, int *tile_scratch, float4 *partial, int log2_chunks, hipStream_t stream) {
+                                  float4 *accum, unsigned long long *counters, int *tile_scratch, int *ordered, float4 *partial, int log2_chunks, hipStream_t stream) {
+    const bool have_order = ordered && *ordered;
+    if (ordered) *ordered = have_order;
     if (p.n_tiles <= 0 || p.s_end <= p.s_begin) return hipSuccess;
     if (ss.n_leaves <= 0 || ss.n_leaves > RTC_SMALL_MAX_LEAVES) return hipErrorInvalidValue;
     if (!partial) log2_chunks = 0;
     const int *perm = nullptr;
-    if (tile_scratch && p.s_end - p.s_begin >= 32 && p.n_tiles >= 2048 && p.max_depth > 0) {
+    if (tile_scratch && have_order) perm = tile_scratch + p.n_tiles;
+    else if (tile_scratch && p.s_end - p.s_begin >= 32 && p.n_tiles >= 2048 && p.max_depth > 0) {
         RenderParams probe = p; probe.s_end = probe.s_begin + 1;
         int *cost = tile_scratch, *order = tile_scratch + p.n_tiles;
         launch_small<true>(ss, sc, cam, probe, accum, counters, nullptr, cost, nullptr, 0, stream);
         hipLaunchKernelGGL(k_tile_order, dim3(1), dim3(1024), 0, stream, cost, p.n_tiles, order);
         perm = order;
+        if (ordered) *ordered = 1;
     }
     launch_small<false>(ss, sc, cam, p, accum, counters, perm, nullptr, partial, log2_chunks, stream);
     if (log2_chunks > 0) {

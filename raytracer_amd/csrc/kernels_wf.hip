@@ -165,7 +165,7 @@ __global__ void __launch_bounds__(kWfExtendBlock) __attribute__((amdgpu_waves_pe
 // ids move (the path state stays where it is in HBM and the block's slots are neighbours, so the gathers stay inside a
 // few cache lines); a wave then runs one arm of the material switch instead of all of them.  No global atomics.
 #ifndef RT_WF_SHADE_BLOCK
-#define RT_WF_SHADE_BLOCK 512
+#define RT_WF_SHADE_BLOCK 1024
 #endif
 constexpr int kWfShadeBlock = RT_WF_SHADE_BLOCK;
 #ifndef RT_WF_SHADE_WAVES

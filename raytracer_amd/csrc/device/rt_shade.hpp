@@ -276,13 +276,16 @@ RT_DEV f3 dielectric_dir(float ir, f3 dir, const RecT<float> &rec, float xi) {  
 
 // Shade one hit.  integrator 0: ray.c:58-83 in loop form (L += T*emitted; T *= att*scattering_pdf/pdf_val).
 // integrator 1/2: 02 main.c:54-62 / 01 main.c:45-56 (T *= attenuation).  xi = this bounce's Philox block.
+// `m` = the material record; resolved = its texture is the constant m.albedo (a leaf_shade record, rtc_tables.h): no table is
+// read at all then.
 template <bool NOISE = true>
-RT_DEV int shade_hit(const SceneT<float> &sc, PathState &ps, const RecT<float> &rec, int integrator, float light_weight, const Rng4 &xi) {
-    const MaterialT<float> m = sc.materials[rec.mat];
+RT_DEV int shade_hit_mat(const SceneT<float> &sc, PathState &ps, const RecT<float> &rec, const MaterialT<float> &m, bool resolved, int integrator,
+                         float light_weight, const Rng4 &xi) {
+    auto tex = [&]() { return resolved ? f3mk(m.albedo[0], m.albedo[1], m.albedo[2]) : texture_value<NOISE>(sc, m.tex, rec.u, rec.v, rec.p); };
     const f3 d = ps.ray.d;
     RayT<float> next; next.o = rec.p; next.time = ps.ray.time;
     if (m.type == RTC_MAT_LIGHT) {                                                     // material.c:229-235 (03: front face only, F15)
-        if (integrator != 2 && (integrator == 1 || rec.front)) ps.L = ps.L + ps.T * texture_value<NOISE>(sc, m.tex, rec.u, rec.v, rec.p);
+        if (integrator != 2 && (integrator == 1 || rec.front)) ps.L = ps.L + ps.T * tex();
         return RT_TERMINATE;                                                           // material_light_scatter returns 0
     }
     if (m.type == RTC_MAT_METAL) {                                                     // material.c:130-138 / 02 :132-141
@@ -299,11 +302,11 @@ RT_DEV int shade_hit(const SceneT<float> &sc, PathState &ps, const RecT<float> &
     if (m.type == RTC_MAT_ISOTROPIC) {                                                 // 02 material.c:173-177; 03's is UB (F14) -> absorb
         if (integrator == 0) return RT_TERMINATE;
         next.d = uniform_ball(xi.x, xi.y, xi.z);
-        ps.T = ps.T * texture_value<NOISE>(sc, m.tex, rec.u, rec.v, rec.p);
+        ps.T = ps.T * tex();
         ps.ray = next; return RT_CONTINUE;
     }
     // lambertian
-    const f3 att = texture_value<NOISE>(sc, m.tex, rec.u, rec.v, rec.p);
+    const f3 att = tex();
     if (integrator != 0) {                                                             // 02 material.c:120-128
         f3 dir = rec.n + uniform_sphere(xi.x, xi.y);
         if (fabsf(dir.x) < 1e-8f && fabsf(dir.y) < 1e-8f && fabsf(dir.z) < 1e-8f) dir = rec.n;
@@ -333,6 +336,12 @@ RT_DEV int shade_hit(const SceneT<float> &sc, PathState &ps, const RecT<float> &
     ps.T = ps.T * (att * (spdf * __builtin_amdgcn_rcpf(pdf_val)));
     next.d = dir; ps.ray = next;
     return RT_CONTINUE;
+}
+
+template <bool NOISE = true>
+RT_DEV int shade_hit(const SceneT<float> &sc, PathState &ps, const RecT<float> &rec, int integrator, float light_weight, const Rng4 &xi) {
+    const MaterialT<float> m = sc.materials[rec.mat];
+    return shade_hit_mat<NOISE>(sc, ps, rec, m, false, integrator, light_weight, xi);
 }
 
 RT_DEV f3 sky_color(f3 dir) {                                                          // 01 main.c:59-64

@@ -435,6 +435,39 @@ void build_bleaves(FlatScene &fs) {
     }
 }
 
+// Shading record of every leaf slot (the wavefront shade stage reads it by the hit's slot): the hit point needs only the
+// ray, the normal a world-space constant (rect: row of the collapsed rotation, like the quad leaf) or centre and 1/r
+// (sphere), the face flags follow hit_record_set_facenormal and the wrappers' re-facing (F11, flip_face), the colour is
+// resolved when the texture is a solid one.  Anything else -- a texture that must be evaluated, a moving sphere, a medium
+// -- is marked RTC_SF_GENERAL and goes through prims / chains / materials / textures as before.
+void build_leaf_shade(FlatScene &fs) {
+    fs.leaf_shade.clear();
+    for (int id : fs.leaf_prims) {
+        const PrimT<double> &p = fs.prims[id];
+        const MaterialT<double> &m = fs.materials[p.mat];
+        SmallShade S; std::memset(&S, 0, sizeof S);
+        double M[9], b[3]; bool wrapped, flip;
+        collapse_chain(fs, p.chain, M, b, wrapped, flip);
+        S.meta = (uint32_t)m.type | (wrapped ? RTC_SF_FORCED_FRONT : 0u) | (flip ? RTC_SF_FLIP : 0u);
+        bool general = p.type != RTC_PRIM_RECT && p.type != RTC_PRIM_SPHERE;
+        if (m.type == RTC_MAT_METAL) { for (int k = 0; k < 3; k++) S.rgb[k] = (float)m.albedo[k]; S.param = (float)m.param; }
+        else if (m.type == RTC_MAT_DIELECTRIC) { S.rgb[0] = S.rgb[1] = S.rgb[2] = 1.0f; S.param = (float)m.param; }
+        else if (m.type == RTC_MAT_ISOTROPIC || m.tex < 0 || fs.textures[m.tex].type != RTC_TEX_SOLID) general = true;
+        else for (int k = 0; k < 3; k++) S.rgb[k] = (float)fs.textures[m.tex].v[k];
+        if (p.type == RTC_PRIM_RECT) {
+            const int e = p.axis == RTC_AXIS_YZ ? 0 : (p.axis == RTC_AXIS_XZ ? 1 : 2);          // outward normal = +axis unit, object space
+            for (int k = 0; k < 3; k++) S.g[k] = (float)M[3 * e + k];                           // world normal = row e of M
+        } else if (p.type == RTC_PRIM_SPHERE) {
+            double cw[3]; to_world_point(M, b, p.d, cw);
+            for (int k = 0; k < 3; k++) S.g[k] = (float)cw[k];
+            S.g[3] = (float)(1.0 / p.d[3]);
+            S.meta |= RTC_SF_SPHERE;
+        }
+        if (general) S.meta |= RTC_SF_GENERAL;
+        fs.leaf_shade.push_back(S);
+    }
+}
+
 // Small-scene pack: eligible when every leaf is a rect or a sphere, there are at most 64 of them, and every
 // lambertian / light texture is a solid colour (so the colour can be resolved here, once, instead of per hit).
 void build_small_pack(FlatScene &fs) {
@@ -664,6 +697,7 @@ bool flatten_scene(const hittable_list *world, const hittable_list *lights, cons
         }
         out.bvh_depth = b.max_depth;
         build_bleaves(out);
+        build_leaf_shade(out);
     }
     return true;
 }

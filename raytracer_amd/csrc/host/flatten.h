@@ -20,6 +20,7 @@ struct FlatScene {
     std::vector<BvhNode> nodes;
     std::vector<int> leaf_prims;
     std::vector<BLeaf> bleaves;     // FP32 traversal leaves, one per slot of leaf_prims
+    std::vector<SmallShade> leaf_shade;   // shading record per slot of leaf_prims (rtc_tables.h SmallShade, RTC_SF_GENERAL)
     int bvh_depth = 0;              // levels of the production BVH (root = 1): bounds the traversal stack
     std::vector<int> box_first;     // first primitive of every hittable box (its 6 sides follow in creation order)
     std::vector<int> box_slots;     // leaf slots where an axis-aligned box record starts (it owns 6 slots: BLeaf, rtc_tables.h)

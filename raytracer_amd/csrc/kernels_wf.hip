@@ -212,12 +212,28 @@ __global__ void __launch_bounds__(kWfShadeBlock) __attribute__((amdgpu_waves_per
             ps.L = ps.T * bg;
             status = RT_TERMINATE;
         } else {
-            const PrimT<float> p = sc.prims[sc.leaf_prims[hslot]];
-            const MaterialT<float> &mat = sc.materials[p.mat];
-            const RecT<float> rec = resolve_hit<float>(sc, ps.ray, p, hh.x, material_needs_uv(sc, mat));
+            const SmallShade sh = sc.leaf_shade[hslot];              // one read instead of leaf_prims -> prims -> chain -> materials -> textures
             const Rng4 xi = rng_block(pixel, (uint32_t)m.x, (uint32_t)m.y, P.seed_lo, P.seed_hi);
-            status = shade_hit<NOISE>(sc, ps, rec, P.integrator, P.light_weight, xi);
-            m.z = p.type == RTC_PRIM_MEDIUM ? -1 : hslot;
+            if (!(sh.meta & RTC_SF_GENERAL)) {
+                RecT<float> rec; rec.u = 0; rec.v = 0; rec.mat = 0;
+                rec.p = ps.ray.o + ps.ray.d * hh.x;                   // ray_at, ray.c:8-11
+                const f3 gv = f3mk(sh.g[0], sh.g[1], sh.g[2]);
+                const f3 n_out = (sh.meta & RTC_SF_SPHERE) ? (rec.p - gv) * sh.g[3] : gv;
+                bool front = dot(ps.ray.d, n_out) < 0.0f;             // hit_record_set_facenormal, hittable.c:13-16
+                rec.n = front ? n_out : -n_out;
+                if (sh.meta & RTC_SF_FORCED_FRONT) front = true;      // translate/rotate re-face an already faced normal (F11)
+                if (sh.meta & RTC_SF_FLIP) front = !front;            // flip_face_hit, hittable.c:587-591
+                rec.front = front;
+                MaterialT<float> mat; mat.type = (int)(sh.meta & 0xffu); mat.tex = -1; mat.albedo[0] = sh.rgb[0]; mat.albedo[1] = sh.rgb[1]; mat.albedo[2] = sh.rgb[2]; mat.param = sh.param;
+                status = shade_hit_mat<NOISE>(sc, ps, rec, mat, true, P.integrator, P.light_weight, xi);
+                m.z = hslot;
+            } else {
+                const PrimT<float> p = sc.prims[sc.leaf_prims[hslot]];
+                const MaterialT<float> &mat = sc.materials[p.mat];
+                const RecT<float> rec = resolve_hit<float>(sc, ps.ray, p, hh.x, material_needs_uv(sc, mat));
+                status = shade_hit<NOISE>(sc, ps, rec, P.integrator, P.light_weight, xi);
+                m.z = p.type == RTC_PRIM_MEDIUM ? -1 : hslot;
+            }
         }
         ++m.y;
         if (status == RT_TERMINATE || m.y >= P.max_depth) {          // ray.c:52: depth exhausted adds nothing

@@ -40,7 +40,7 @@ struct DevBuf {
 };
 
 template <typename R> struct DeviceTables {
-    DevBuf prims, bprims, ops, chains, materials, textures, lights, perlin_vec, perlin_perm, images, image_data, nodes, leaf_prims, bleaves, ref_steps, ref_boxes;
+    DevBuf prims, bprims, ops, chains, materials, textures, lights, perlin_vec, perlin_perm, images, image_data, nodes, leaf_prims, bleaves, leaf_shade, ref_steps, ref_boxes;
     SceneT<R> view;
     bool ready = false;
 };
@@ -64,7 +64,7 @@ template <typename R> hipError_t upload_tables(const FlatScene &fs, DeviceTables
     UP(prims, prims); UP(bprims, bprims); UP(ops, ops); UP(chains, fs.chains); UP(materials, mats); UP(textures, texs); UP(lights, lights);
     UP(perlin_vec, pvec); UP(perlin_perm, fs.perlin_perm); UP(images, fs.images); UP(image_data, fs.image_data); UP(nodes, fs.nodes); UP(leaf_prims, fs.leaf_prims);
     if (with_ref_steps) { UP(ref_steps, fs.ref_steps); UP(ref_boxes, fs.ref_boxes); }
-    else UP(bleaves, fs.bleaves);
+    else { UP(bleaves, fs.bleaves); UP(leaf_shade, fs.leaf_shade); }
 #undef UP
     SceneT<R> &v = dt.view;
     v.prims = (const PrimT<R> *)dt.prims.p; v.n_prims = (int)fs.prims.size();
@@ -76,7 +76,7 @@ template <typename R> hipError_t upload_tables(const FlatScene &fs, DeviceTables
     v.perlin_vec = (const R *)dt.perlin_vec.p; v.perlin_perm = (const int *)dt.perlin_perm.p;
     v.images = (const ImageDesc *)dt.images.p; v.image_data = (const unsigned char *)dt.image_data.p;
     v.nodes = (const BvhNode *)dt.nodes.p; v.leaf_prims = (const int *)dt.leaf_prims.p; v.n_nodes = (int)fs.nodes.size();
-    v.bleaves = (const BLeaf *)dt.bleaves.p;
+    v.bleaves = (const BLeaf *)dt.bleaves.p; v.leaf_shade = (const SmallShade *)dt.leaf_shade.p;
     v.ref_steps = (const RefStep *)dt.ref_steps.p; v.ref_boxes = (const double *)dt.ref_boxes.p;
     v.n_ref_steps = with_ref_steps ? (int)fs.ref_steps.size() : 0;
     v.bvh_depth = fs.bvh_depth < 1 ? 1 : (fs.bvh_depth > RTC_BVH_MAX_DEPTH ? RTC_BVH_MAX_DEPTH : fs.bvh_depth);

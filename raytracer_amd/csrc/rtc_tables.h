@@ -78,6 +78,7 @@ template <typename R> struct SceneT {
     const ImageDesc *images; const unsigned char *image_data;
     const BvhNode *nodes;    const int *leaf_prims; int n_nodes;   // n_nodes == 0: brute-force loop over prims
     const BLeaf *bleaves;                                          // FP32 production BVH only (NULL in the FP64 tables)
+    const struct SmallShade *leaf_shade;                           // per leaf slot: everything shading needs of a resolved leaf, one 48-byte read
     int bvh_depth;           // levels of the BVH = entries the traversal stack needs
     const RefStep *ref_steps; const double *ref_boxes; int n_ref_steps;   // FP64 check path; boxes = min xyz, max xyz
     int n_media;             // media among prims (stochastic hits)
@@ -102,7 +103,8 @@ template <typename R> struct SceneT {
 // Leaf ids (SmallShade index, `src`): rects first (a pair names its two ids in f[10], f[11] as int bits, a box in its id
 // bytes), then sphere s -> n_rects + s.
 enum { RTC_SMALL_MAX_LEAVES = 64, RTC_SMALL_MAX_XFORMS = 16 };
-enum { RTC_SF_FORCED_FRONT = 1u << 8, RTC_SF_FLIP = 1u << 9, RTC_SF_SPHERE = 1u << 10 };   // SmallShade.meta bits; bits 0-7 = material type
+enum { RTC_SF_FORCED_FRONT = 1u << 8, RTC_SF_FLIP = 1u << 9, RTC_SF_SPHERE = 1u << 10,   // SmallShade.meta bits; bits 0-7 = material type
+       RTC_SF_GENERAL = 1u << 11 };   // BVH leaf_shade only: not resolvable here (texture lookup, moving sphere, medium) -> prims / materials / textures
 struct alignas(64) SmallPair { float f[16]; };
 struct alignas(32) SmallGroup { int xform, first, n_xy, n_xz, n_yz, box, pad1, pad2; };   // box >= 0: SmallBox of this space, tested before the pairs
 // Rects of one object space that are faces of ONE axis-aligned box -- all six (hittable_box_new, hittable.c:139-155) or

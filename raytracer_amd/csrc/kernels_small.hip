@@ -182,46 +182,70 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) k
     if (!PROBE && tile_perm) tile = tile_perm[tile];   // heaviest tiles first (launch_pathtrace_small)
     const int spp_all = P.s_end - P.s_begin, q = spp_all >> log2_chunks, r = spp_all & ((1 << log2_chunks) - 1);
     const int s_lo = P.s_begin + chunk * q + (chunk < r ? chunk : r), s_hi = s_lo + q + (chunk < r ? 1 : 0);
-    const int px = (tile % P.tiles_x) * 8 + (lane & 7), py = (tile / P.tiles_x) * 8 + (lane >> 3);
-    const bool valid = px < P.width && py < P.height;
-    const uint32_t pixel = (uint32_t)(py * P.width + px);
+    // Lanes are not pixels.  The 64 * S paths of the work item (64 pixels x S samples) are numbered q = sample * 64 + pixel
+    // and handed out in that order to whichever lanes need a path (a wave-uniform counter and a prefix count: no atomics).
+    // With a lane per pixel, the lane of a border pixel (one ray per sample) ran out of work long before the lane of an
+    // interior pixel (five) and 9.5 % of the lane-iterations idled; now all lanes finish within a path of each other
+    // (fill 0.986).  A finished path is added to the tile's sums in LDS (ds_add_f32; one wave, lock-step: the order is fixed,
+    // the result reproducible; consecutive paths are different pixels, so the lanes that finish together rarely meet on an
+    // address -- numbering the paths pixel-major put whole waves on one address and cost 10-16 %); lane l writes pixel l of
+    // the tile at the end.
+    __shared__ float lds_sum[4][64 * 3];
+    float *const tile_sum = lds_sum[threadIdx.x >> 6];
+    tile_sum[lane] = 0.0f; tile_sum[64 + lane] = 0.0f; tile_sum[128 + lane] = 0.0f;
+    const int tx0 = (tile % P.tiles_x) * 8, ty0 = (tile / P.tiles_x) * 8;
+    const int S = s_hi - s_lo, n_paths = 64 * S;
     const float inv_w = 1.0f / (float)(P.width - 1), inv_h = 1.0f / (float)(P.height - 1);
     const f3 bg = f3mk(sc.background[0], sc.background[1], sc.background[2]);
 
-    f3 sum = f3mk(0, 0, 0), T = f3mk(1, 1, 1), L = f3mk(0, 0, 0), ro = f3mk(0, 0, 0), rd = f3mk(0, 0, 1);
+    f3 T = f3mk(1, 1, 1), L = f3mk(0, 0, 0), ro = f3mk(0, 0, 0), rd = f3mk(0, 0, 1);
     unsigned nrays = 0, iters = 0;
-    int s_next = s_lo, depth = 0, src = -1;
-    uint32_t s_cur = 0;
+    int q_next = 0;                                                       // wave-uniform: paths handed out so far
+    int depth = 0, src = -1, cur_pix = 0;
+    uint32_t s_cur = 0, pixel = 0;
     bool alive = false;
+    auto locate = [&](int q, int &pix, uint32_t &smp) { pix = q & 63; smp = (uint32_t)(s_lo + (q >> 6)); };   // path q -> pixel of the tile, sample
     // Primary rays are generated ahead, two per lane (b0 is used first): a third of the lanes ends a path in every
     // iteration, so generating on demand runs the camera code (a Philox block and the ray set-up) in EVERY iteration
     // for a third of the wave; filled only when some lane has run dry, it runs every few iterations for most of it
     // (a third buffered ray changes nothing).  6 waves/SIMD = 80 VGPRs without spills: 24.6 ms at 5 waves, 23.3 at 6, 23.6
-    // at 7 (5 spilled), 24.9 at 8 (15 spilled).
+    // at 7 (5 spilled), 24.9 at 8 (15 spilled).  A pixel outside the image (ragged right / top edge) buffers a zero direction.
     f3 b0d = rd, b1d = rd, b0o = ro, b1o = ro;
-    int n_buf = 0;                                                        // buffered samples: s_next - n_buf .. s_next - 1
-    auto primary = [&](uint32_t s, f3 &o, f3 &d) {                        // main.c:150-152 + camera.c:46-53
-        const Rng4 c = rng_block(pixel, s, RT_TAG_CAMERA, P.seed_lo, P.seed_hi);
+    int b0q = 0, b1q = 0, n_buf = 0;                                      // buffered paths and their numbers
+    auto primary = [&](int q, f3 &o, f3 &d) {                             // main.c:150-152 + camera.c:46-53
+        int pix; uint32_t smp; locate(q, pix, smp);
+        const int px = tx0 + (pix & 7), py = ty0 + (pix >> 3);
+        const Rng4 c = rng_block((uint32_t)(py * P.width + px), smp, RT_TAG_CAMERA, P.seed_lo, P.seed_hi);
         const float u = ((float)px + c.x) * inv_w, v = ((float)py + c.y) * inv_h;
         float dx = 0.0f, dy = 0.0f;
         if (LENS) { const float rr = __builtin_amdgcn_sqrtf(c.z); dx = rr * cos2pi(c.w); dy = rr * sin2pi(c.w); }
         const RayT<float> r = camera_ray<float>(cam, u, v, dx, dy, 0.0f);   // no leaf moves: the ray time is never read
-        o = r.o; d = r.d;
+        o = r.o; d = (px < P.width && py < P.height) ? r.d : f3mk(0, 0, 0);
+    };
+    // the next paths go to the lanes of `want`, in lane order
+    auto hand_out = [&](bool want, int &q) -> bool {
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(want);
+        q = q_next + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+        q_next += (int)__builtin_popcountll(m);
+        return want && q < n_paths;
     };
 
     for (;;) {
         if (P.max_depth <= 0) break;                                       // ray.c:52
-        const bool starving = !alive && valid && n_buf == 0 && s_next < s_hi;
-        if (__builtin_amdgcn_ballot_w64(starving) != 0) {
-            if (valid && n_buf == 0 && s_next < s_hi) { primary((uint32_t)s_next++, b0o, b0d); n_buf = 1; }
-            if (valid && n_buf == 1 && s_next < s_hi) { primary((uint32_t)s_next++, b1o, b1d); n_buf = 2; }
+        const bool starving = !alive && n_buf == 0;
+        if (q_next < n_paths && __builtin_amdgcn_ballot_w64(starving) != 0) {
+            int q;
+            if (hand_out(n_buf == 0, q)) { primary(q, b0o, b0d); b0q = q; n_buf = 1; }
+            if (hand_out(n_buf == 1, q)) { primary(q, b1o, b1d); b1q = q; n_buf = 2; }
         }
         if (!alive && n_buf > 0) {
-            s_cur = (uint32_t)(s_next - n_buf); --n_buf;
-            rd = b0d; b0d = b1d;
+            locate(b0q, cur_pix, s_cur); --n_buf;
+            pixel = (uint32_t)((ty0 + (cur_pix >> 3)) * P.width + tx0 + (cur_pix & 7));
+            rd = b0d; b0d = b1d; b0q = b1q;
             if (LENS) { ro = b0o; b0o = b1o; } else ro = f3mk(cam.origin[0], cam.origin[1], cam.origin[2]);
             T = f3mk(1, 1, 1); L = f3mk(0, 0, 0);
-            depth = 0; alive = true; src = -1;
+            depth = 0; src = -1;
+            alive = rd.x != 0.0f || rd.y != 0.0f || rd.z != 0.0f;          // a pixel outside the image: nothing to trace
         }
         if (__builtin_amdgcn_ballot_w64(alive) == 0) break;
         ++iters;
@@ -293,7 +317,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) k
             if (done || depth >= P.max_depth) {
                 alive = false;
                 const bool finite = (fabsf(L.x) < 3.0e38f) && (fabsf(L.y) < 3.0e38f) && (fabsf(L.z) < 3.0e38f);
-                if (finite) sum = sum + L;
+                // (most paths of a scene with a black background end with nothing to add: no LDS traffic for those)
+                if (finite && (L.x != 0.0f || L.y != 0.0f || L.z != 0.0f)) { atomicAdd(&tile_sum[cur_pix], L.x); atomicAdd(&tile_sum[64 + cur_pix], L.y); atomicAdd(&tile_sum[128 + cur_pix], L.z); }
             }
         }
     }
@@ -301,12 +326,15 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) k
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) total += __shfl_xor(total, off, 64);
     if (PROBE) { if (lane == 0) tile_cost[tile] = (int)total; return; }   // cost probe: rays of this tile, nothing else is written
-    if (valid) {
+    const int px = tx0 + (lane & 7), py = ty0 + (lane >> 3);
+    if (px < P.width && py < P.height) {                                   // lane l writes pixel l of the tile
+        const size_t pix_id = (size_t)py * P.width + px;
+        const f3 sum = f3mk(tile_sum[lane], tile_sum[64 + lane], tile_sum[128 + lane]);
         if (log2_chunks == 0) {                                            // the only wave of this pixel: straight into the accumulator
-            float4 a = accum[pixel];
+            float4 a = accum[pix_id];
             a.x += sum.x; a.y += sum.y; a.z += sum.z; a.w += (float)(s_hi - s_lo);
-            accum[pixel] = a;
-        } else partial[(size_t)chunk * ((size_t)P.width * P.height) + pixel] = make_float4(sum.x, sum.y, sum.z, (float)(s_hi - s_lo));
+            accum[pix_id] = a;
+        } else partial[(size_t)chunk * ((size_t)P.width * P.height) + pix_id] = make_float4(sum.x, sum.y, sum.z, (float)(s_hi - s_lo));
     }
     if (lane == 0) { atomicAdd(counters, (unsigned long long)total); atomicAdd(counters + 1, (unsigned long long)iters); }
 }

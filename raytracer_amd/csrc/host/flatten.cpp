@@ -260,7 +260,7 @@ struct Builder {
     std::vector<int> &leaf_prims;
     const std::vector<BuildItem> &items;
     std::vector<int> &box_slots;
-    static constexpr int kLeafMax = 4, kBins = 16;
+    static constexpr int kLeafMax = 2, kBins = 16;
     struct Child { int child, count; Box box; };
 
     static double area(const Box &b) { double d[3] = {b.hi[0] - b.lo[0], b.hi[1] - b.lo[1], b.hi[2] - b.lo[2]}; return 2.0 * (d[0] * d[1] + d[1] * d[2] + d[2] * d[0]); }

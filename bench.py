@@ -45,8 +45,8 @@ PEAK_L2_GBS = 34500.0             # MI355X_MICROARCH.md: 8 x 4 MiB L2, ~34.5 TB/
 # BVH scenes (wavefront kernels): measured traversal steps per ray (probe builds RT_EXP=3/4) ->
 # algorithmic bytes per ray = (node steps + leaf steps) x 64 B (node and traversal leaf are both 64 B; steps measured with
 # the RT_EXP=3/4 probe builds) + 166 B of path-slot state per bounce (extend 48 R + 9 W, shade 61 R + 48 W)
-SCENE_BYTES = {"final": (9.4 + 5.5) * 64 + 166, "final_earth": (9.1 + 4.8) * 64 + 166, "book1": (8.7 + 3.8) * 64 + 166,
-               "million": (22.7 + 4.3) * 64 + 166}
+SCENE_BYTES = {"final": (10.4 + 3.3) * 64 + 166, "final_earth": (10.0 + 2.7) * 64 + 166, "book1": (9.5 + 2.4) * 64 + 166,
+               "million": (23.6 + 2.7) * 64 + 166}
 
 
 def measured_traffic():

@@ -67,6 +67,16 @@ rtc_scene *rtc_scene_build(const hittable_list *world, const hittable_list *ligh
  * without a GPU.  Compute entry points return RTC_ERR_DEVICE for such a handle. */
 rtc_scene *rtc_scene_flatten_only(const hittable_list *world, const hittable_list *lights, const color *background,
                                   double time0, double time1);
+/* A flattened scene on disk.  No reference counterpart: the reference's scenes are C functions that draw rand() while
+ * they build (03 main.c:28-78, 02 main.c:76-289, 01 main.c:81-114), so a scene exists only inside the process that built
+ * it; a scene file makes it a fixture and skips the flatten + BVH build (1.2 s for 1M spheres).
+ * rtc_scene_save writes the tables of any handle.  rtc_scene_load reads them back, verifies the checksum, the table
+ * layouts and every index a kernel follows, and uploads them to the current device; rtc_scene_load_host stops before
+ * the upload (a handle like rtc_scene_flatten_only's).  NULL + rtc_last_error() on any failure; a file that loads renders
+ * bit-identically to the scene it was saved from. */
+int        rtc_scene_save(const rtc_scene *scene, const char *path);
+rtc_scene *rtc_scene_load(const char *path);
+rtc_scene *rtc_scene_load_host(const char *path);
 void rtc_scene_free(rtc_scene *scene);
 /* Number of flattened leaf primitives (visit order of the reference's traversal = primitive id). */
 int  rtc_scene_num_prims(const rtc_scene *scene);

@@ -68,7 +68,7 @@ hittable_list_index hittable_list_objects hittable_list_free hittable_lists_free
 hittable_rect_new hittable_box_new hittable_moving_sphere_new bvh_node_init hittable_translate_init
 hittable_rotate_init hittable_constant_medium_init hittable_constant_medium_init_c hittable_flip_face_init
 hittable_free camera_new camera_free camera_fields rt_scene_build rt_scene_set_image_path rt_write_png rt_write_ppm_p3""".split()
-RTC_SYMBOLS = """rtc_init rtc_last_error rtc_device_name rtc_scene_build rtc_scene_flatten_only rtc_scene_free rtc_scene_num_prims
+RTC_SYMBOLS = """rtc_init rtc_last_error rtc_device_name rtc_scene_build rtc_scene_flatten_only rtc_scene_save rtc_scene_load rtc_scene_load_host rtc_scene_free rtc_scene_num_prims
 rtc_scene_dump_leaves rtc_scene_bvh_info rtc_scene_dump_bvh rtc_first_hit_f64 rtc_first_hit_f32 rtc_primary_first_hit_f64 rtc_render_device rtc_render rtc_render_stats
 rtc_tonemap_u8_device rtc_tonemap_u8 make_scene free_scene render_scene render_scene_accumulate""".split()
 
@@ -95,7 +95,8 @@ def lib():
                  "material_isotropic_new", "hittable_list_new", "hittable_list_new_no_gc", "hittable_sphere_new",
                  "hittable_rect_new", "hittable_box_new", "hittable_moving_sphere_new", "bvh_node_init",
                  "hittable_translate_init", "hittable_rotate_init", "hittable_constant_medium_init_c",
-                 "hittable_flip_face_init", "camera_new", "rt_scene_build", "rtc_scene_build", "rtc_scene_flatten_only"):
+                 "hittable_flip_face_init", "camera_new", "rt_scene_build", "rtc_scene_build", "rtc_scene_flatten_only",
+                 "rtc_scene_load", "rtc_scene_load_host"):
         getattr(L, name).restype = _P
     L.texture_solid_color_init.argtypes = [Vec3]
     L.texture_checker_init.argtypes = [_P, _P]
@@ -133,6 +134,9 @@ def lib():
     L.rtc_device_name.restype = C.c_char_p
     L.rtc_scene_build.argtypes = [_P, _P, C.POINTER(Vec3), C.c_double, C.c_double]
     L.rtc_scene_flatten_only.argtypes = [_P, _P, C.POINTER(Vec3), C.c_double, C.c_double]
+    L.rtc_scene_save.argtypes = [_P, C.c_char_p]
+    L.rtc_scene_load.argtypes = [C.c_char_p]
+    L.rtc_scene_load_host.argtypes = [C.c_char_p]
     L.rtc_scene_free.argtypes = [_P]
     L.rtc_scene_num_prims.argtypes = [_P]
     L.rtc_scene_dump_leaves.argtypes = [_P, _dp, C.c_int]
@@ -203,6 +207,19 @@ class Scene:
         self.handle = build(world, lights, C.byref(bg), time0, time1)
         if not self.handle:
             raise RtcError("rtc_scene_build: " + lib().rtc_last_error().decode())
+
+    @classmethod
+    def load(cls, path, view=None, host_only=False):
+        """rtc_scene_load / rtc_scene_load_host: a scene saved with save(); the file is verified before anything is uploaded."""
+        self = cls.__new__(cls)
+        self.world, self.lights, self.view = None, None, view
+        self.handle = (lib().rtc_scene_load_host if host_only else lib().rtc_scene_load)(os.fsencode(path))
+        if not self.handle:
+            raise RtcError(lib().rtc_last_error().decode())
+        return self
+
+    def save(self, path):
+        _check(lib().rtc_scene_save(self.handle, os.fsencode(path)), "rtc_scene_save")
 
     def close(self):
         if self.handle:

@@ -3,7 +3,9 @@
  * Keeps the reference's flags (03_FullTracer/main.c:93-105: -w width, -h height, -o outputFile, -s samples) and
  * its PNG output (vertical flip, main.c:170-171); the OpenMP pixel loop (main.c:137-167) is replaced by
  * rtc_render on the GPU.  Extra flags: -S scene id (default 1 = Cornell box; the reference hard-codes the scene),
- * -a aspect (default W/H; the reference hard-codes 1.0), -d depth, -r seed, -A arg (scene size).
+ * -a aspect (default W/H; the reference hard-codes 1.0), -d depth, -r seed, -A arg (scene size),
+ * -W file (write the flattened scene, rtc_scene_save), -L file (render that file instead of flattening scene -S again;
+ * -S still names the camera).
  */
 #include <stdio.h>
 #include <stdlib.h>
@@ -15,7 +17,7 @@
 static double now_s(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
 
 int main(int argc, char **argv) {
-    const char *out = "output.png";
+    const char *out = "output.png", *save_path = NULL, *load_path = NULL;
     int W = 1024, H = -1, spp = 256, depth = -1, scene_id = RT_SCENE_CORNELL, arg = 0;
     double aspect = -1; unsigned long long seed = 0;
     for (int i = 1; i < argc; i++) {
@@ -31,8 +33,10 @@ int main(int argc, char **argv) {
         case 'd': depth = atoi(argv[i + 1]); break;
         case 'r': seed = strtoull(argv[i + 1], NULL, 0); break;
         case 'A': arg = atoi(argv[i + 1]); break;
+        case 'W': save_path = argv[i + 1]; break;
+        case 'L': load_path = argv[i + 1]; break;
         default:
-            fprintf(stderr, "Usage: %s [-w width] [-h height] [-o outputFile] [-s sample_per_pixel] [-S scene] [-a aspect] [-d depth] [-r seed] [-A scene_arg]\n", argv[0]);
+            fprintf(stderr, "Usage: %s [-w width] [-h height] [-o outputFile] [-s sample_per_pixel] [-S scene] [-a aspect] [-d depth] [-r seed] [-A scene_arg] [-W scene_file_out] [-L scene_file_in]\n", argv[0]);
             return EXIT_FAILURE;
         }
         i++;
@@ -49,8 +53,9 @@ int main(int argc, char **argv) {
     camera *cam = camera_new(view.lookfrom, view.lookat, view.vup, view.vfov, aspect, view.aperture, view.focus_dist, view.time0, view.time1);
 
     double t0 = now_s();
-    rtc_scene *scene = rtc_scene_build(world, lights, &view.background, view.time0, view.time1);
-    if (!scene) { fprintf(stderr, "rtc_scene_build: %s\n", rtc_last_error()); return EXIT_FAILURE; }
+    rtc_scene *scene = load_path ? rtc_scene_load(load_path) : rtc_scene_build(world, lights, &view.background, view.time0, view.time1);
+    if (!scene) { fprintf(stderr, "%s\n", rtc_last_error()); return EXIT_FAILURE; }
+    if (save_path && rtc_scene_save(scene, save_path) != RTC_OK) { fprintf(stderr, "%s\n", rtc_last_error()); return EXIT_FAILURE; }
     double t1 = now_s();
     rtc_settings st; memset(&st, 0, sizeof st);
     st.width = W; st.height = H; st.max_depth = depth; st.sample_begin = 0; st.sample_end = spp;
@@ -63,7 +68,7 @@ int main(int argc, char **argv) {
     if (rtc_tonemap_u8(accum, W, H, pixels) != RTC_OK) { fprintf(stderr, "rtc_tonemap_u8: %s\n", rtc_last_error()); return EXIT_FAILURE; }
     if (!rt_write_png(out, W, H, pixels, 1)) { fprintf(stderr, "could not write %s\n", out); return EXIT_FAILURE; }
     double t3 = now_s();
-    printf("%s: %d prims, scene build %.3f s\n", rtc_device_name(), rtc_scene_num_prims(scene), t1 - t0);
+    printf("%s: %d prims, scene %s %.3f s\n", rtc_device_name(), rtc_scene_num_prims(scene), load_path ? "load" : "build", t1 - t0);
     printf("Time elpased for rendering %f\n", t2 - t1);
     printf("kernel %.3f ms: %.1f Msamples/s, %.1f Mrays/s (%.2f rays/sample); png %.3f s -> %s\n", stats.kernel_ms,
            stats.samples / stats.kernel_ms * 1e-3, stats.rays / stats.kernel_ms * 1e-3, (double)stats.rays / (double)stats.samples, t3 - t2, out);

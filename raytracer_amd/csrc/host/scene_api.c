@@ -124,11 +124,25 @@ void hittable_list_add(hittable_list *l, hittable *o) {
 }
 int hittable_list_index(hittable_list *l) { return l->index; }
 void *hittable_list_objects(hittable_list *l) { return (void *)l->objs; }
+static void list_free_members(hittable_list *l) {
+    if (!l->gc) return;   /* a no-gc list keeps its entries: the BVH built over it frees them (hittable_free) */
+    for (int i = 0; i < l->index; i++) hittable_free(l->objs[i]);
+    l->index = 0;
+}
 void hittable_list_free(hittable_list *l) {
-    if (l->gc) for (int i = 0; i < l->index; i++) hittable_free(l->objs[i]);
+    if (l == NULL) return;
+    for (int i = 0; i < g_lists.n; i++) if (g_lists.v[i] == l) g_lists.v[i] = NULL;   /* hittable_lists_free_all must not see it again */
+    list_free_members(l);
     free(l->objs); free(l);
 }
-void hittable_lists_free_all(void) { for (int i = 0; i < g_lists.n; i++) hittable_list_free((hittable_list *)g_lists.v[i]); g_lists.n = 0; }
+/* Members first, the lists themselves afterwards: a BVH node reads its source list while it is freed (hittable_free),
+ * and that list may have been registered -- and so would have been freed -- before the list that owns the node
+ * (02 main.c:232-254: the box list exists before `objects`). */
+void hittable_lists_free_all(void) {
+    for (int i = 0; i < g_lists.n; i++) if (g_lists.v[i]) list_free_members((hittable_list *)g_lists.v[i]);
+    for (int i = 0; i < g_lists.n; i++) if (g_lists.v[i]) { hittable_list *l = (hittable_list *)g_lists.v[i]; free(l->objs); free(l); }
+    g_lists.n = 0;
+}
 
 /* ---- hittables ------------------------------------------------------------------------------ */
 static hittable *hit_alloc(hittable_list *world, rt_hit_kind kind) {

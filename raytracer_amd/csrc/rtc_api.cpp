@@ -18,6 +18,7 @@
 // `struct texture` (reference name, texture.h:20) is renamed inside this translation unit only.
 #define texture rtc_host_texture
 #include "host/flatten.h"
+#include "host/scene_io.h"
 #include "rtc.h"
 
 namespace {
@@ -143,11 +144,9 @@ const char *rtc_device_name(void) {
     return name;
 }
 
-rtc_scene *rtc_scene_build(const hittable_list *world, const hittable_list *lights, const color *background, double time0, double time1) {
-    rtc_scene *s = new rtc_scene();
-    // brute force up to 64 leaves: the uniform loop runs out of SGPR-fed scalar loads; above that the linear BVH wins
-    if (!flatten_scene(world, lights, background, time0, time1, 64, s->flat)) { g_error = "flatten: " + s->flat.error; delete s; return nullptr; }
-    if (hipGetDevice(&s->device) != hipSuccess) { g_error = "rtc_scene_build: no current HIP device"; delete s; return nullptr; }
+// device tables of a flattened scene on the current device (rtc_scene_build and rtc_scene_load)
+static rtc_scene *upload_scene(rtc_scene *s, const char *who) {
+    if (hipGetDevice(&s->device) != hipSuccess) { g_error = std::string(who) + ": no current HIP device"; delete s; return nullptr; }
     hipError_t e = upload_tables<float>(s->flat, s->f32, false);
     std::vector<unsigned char> zero(wf_stats_bytes() + 64, 0);   // [0] rays, [1] wave bounce-iterations, striped wavefront statistics, 16 queue counters
     if (e == hipSuccess) e = s->ray_counter.upload(zero.data(), zero.size());
@@ -167,13 +166,37 @@ rtc_scene *rtc_scene_build(const hittable_list *world, const hittable_list *ligh
         m.n_rects = fs.small_n_rects; m.n_pairs = (int)fs.small_pairs.size(); m.n_groups = (int)fs.small_groups.size(); m.n_spheres = (int)fs.small_spheres.size();
         m.n_xforms = (int)fs.small_xforms.size(); m.n_leaves = (int)fs.small_shade.size(); m.any_fuzz = fs.small_any_fuzz;
     }
-    if (e != hipSuccess) { g_error = std::string("rtc_scene_build: upload failed: ") + hipGetErrorString(e); delete s; return nullptr; }
+    if (e != hipSuccess) { g_error = std::string(who) + ": upload failed: " + hipGetErrorString(e); delete s; return nullptr; }
     return s;
+}
+
+rtc_scene *rtc_scene_build(const hittable_list *world, const hittable_list *lights, const color *background, double time0, double time1) {
+    rtc_scene *s = new rtc_scene();
+    // brute force up to 64 leaves: the uniform loop runs out of SGPR-fed scalar loads; above that the linear BVH wins
+    if (!flatten_scene(world, lights, background, time0, time1, 64, s->flat)) { g_error = "flatten: " + s->flat.error; delete s; return nullptr; }
+    return upload_scene(s, "rtc_scene_build");
 }
 rtc_scene *rtc_scene_flatten_only(const hittable_list *world, const hittable_list *lights, const color *background, double time0, double time1) {
     rtc_scene *s = new rtc_scene();
     if (!flatten_scene(world, lights, background, time0, time1, 64, s->flat)) { g_error = "flatten: " + s->flat.error; delete s; return nullptr; }
     return s;   // device == -1: every compute entry point refuses this handle
+}
+int rtc_scene_save(const rtc_scene *scene, const char *path) {
+    if (!scene || !path) return fail(RTC_ERR_ARG, "rtc_scene_save: null argument");
+    std::string err;
+    if (!save_flat_scene(scene->flat, path, err)) return fail(RTC_ERR_ARG, "rtc_scene_save: " + err);
+    return RTC_OK;
+}
+rtc_scene *rtc_scene_load_host(const char *path) {
+    if (!path) { g_error = "rtc_scene_load: null path"; return nullptr; }
+    rtc_scene *s = new rtc_scene();
+    std::string err;
+    if (!load_flat_scene(path, s->flat, err)) { g_error = "rtc_scene_load: " + err; delete s; return nullptr; }
+    return s;   // device == -1, like rtc_scene_flatten_only
+}
+rtc_scene *rtc_scene_load(const char *path) {
+    rtc_scene *s = rtc_scene_load_host(path);
+    return s ? upload_scene(s, "rtc_scene_load") : nullptr;
 }
 void rtc_scene_free(rtc_scene *scene) { delete scene; }
 int rtc_scene_num_prims(const rtc_scene *scene) { return scene ? (int)scene->flat.prims.size() : RTC_ERR_ARG; }

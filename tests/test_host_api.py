@@ -183,3 +183,36 @@ def test_product_does_not_reference_the_oracle():
                 if re.search(r"cpu_ref|liboracle|hx_|orc_", txt) and fn != "scenes.c":
                     bad.append(os.path.join(dp, fn))
     assert not bad, bad
+
+
+def test_registries_free_every_scene(rtc):
+    """hittable_lists_free_all / materials_free_all / textures_free_all (hittable_list.c:80-84, material.c:19-23,
+    texture.c:92-96) after every built-in scene, in a child process so that a bad free cannot take pytest with it: a BVH
+    node reads its source list while it is freed, and that list is registered before the list that owns the node
+    (02 main.c:232-254) -- freeing list by list in registration order crashed on the final scene."""
+    import subprocess
+    import sys
+    code = """
+import ctypes as C, sys
+sys.path.insert(0, %r)
+import raytracer_amd as ra
+L = ra.lib()
+L.rt_scene_set_image_path(ra.api.EARTHMAP.encode())
+for name, sid in sorted(ra.api.SCENES.items(), key=lambda kv: kv[1]):
+    for rep in range(2):
+        L.srand(C.c_uint(1))
+        lights = L.hittable_list_new_no_gc(64)
+        view = ra.api.SceneView()
+        world = L.rt_scene_build(sid, 40 if name == "million" else 0, lights, C.byref(view))
+        assert world, name
+        n = L.hittable_list_index(world)
+        L.hittable_lists_free_all(); L.materials_free_all(); L.textures_free_all()
+one = L.hittable_list_new(4)
+L.hittable_sphere_new(one, ra.api.v3((0, 0, 0)), 1.0, L.material_dielectric_new(1.5))
+L.hittable_list_free(C.c_void_p(one))         # by hand, then the sweep must not free it again
+L.hittable_lists_free_all(); L.materials_free_all(); L.textures_free_all()
+print("freed", len(ra.api.SCENES))
+""" % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MALLOC_CHECK_="3", MALLOC_PERTURB_="165")   # glibc: abort on a double free, poison freed memory
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, timeout=300, env=env)
+    assert out.returncode == 0 and b"freed 15" in out.stdout, out.stderr.decode()[-2000:]

@@ -7,7 +7,7 @@
 //    regenerates its next sample in the same iteration, so the wave stays full until its tile runs out of samples;
 //  * the primitive loop index is wave-uniform: the scene tables of a small scene (Cornell: 13 leaves) are fetched
 //    with scalar loads into SGPRs -- no VGPRs, no vector memory traffic, nothing to miss in HBM;
-//  * material / pdf dispatch is a switch (rt_shade.hpp); random numbers are Philox4x32-10 on (pixel, sample, bounce).
+//  * material / pdf dispatch is a switch (rt_shade.hpp); random numbers are Philox4x32-7 on (pixel, sample, bounce).
 #include <hip/hip_runtime.h>
 
 #include "device/rt_shade.hpp"

@@ -12,7 +12,7 @@
 //     generic path chases prim -> material -> texture through three dependent global loads;
 //   * material / pdf dispatch is a switch on the record's type; lambertian sampling uses n + uniform-sphere (the same
 //     cosine law as onb.c + random_cosine_direction, without building the basis), the mixture pdf of pdf.c:119-121;
-//   * Philox4x32-10 on (pixel, sample, bounce); 2 blocks per path start are not needed here (no lens, no moving leaf).
+//   * Philox4x32-7 on (pixel, sample, bounce); 2 blocks per path start are not needed here (no lens, no moving leaf).
 // 90 VGPRs -> 5 waves per SIMD, which is enough to hide the scalar-load and LDS latencies: the SIMDs issue VALU
 // instructions 96 % of the time (profiles/r01c), so the remaining lever is the instruction count, not occupancy.
 #include <hip/hip_runtime.h>

@@ -542,6 +542,7 @@ void build_small_pack(FlatScene &fs) {
     while (i < n_rects) {
         SmallGroup g; std::memset(&g, 0, sizeof g);
         g.xform = items[i].key / 4; g.first = (int)pairs.size(); g.box = -1;
+        { const SmallXform &X = xf[(size_t)g.xform]; g.rot_y = X.m[1] == 0.0f && X.m[3] == 0.0f && X.m[5] == 0.0f && X.m[7] == 0.0f && X.m[4] == 1.0f; }
         size_t end = i;
         while (end < n_rects && items[end].key / 4 == g.xform) end++;
         // ---- the largest set of rects of this space that are faces of ONE axis-aligned box (SmallBox, rtc_tables.h) ----

@@ -53,7 +53,7 @@ RT_DEV void small_pair(const SmallPair &P, float on, float in, v2f oab, v2f dab,
         const bool hit = viol <= 0.0f;
         h.t = hit ? t.x : h.t; h.leaf = hit ? id0 : h.leaf;
     }
-    {
+    if (id1 >= 0) {   // wave-uniform (a scalar compare): the run had an odd number of rects and this is its padding
         const v2f p = oab + dab * t.y;
         const v2f lo = {P.f[6], P.f[7]}, hi = {P.f[8], P.f[9]};
         const v2f vl = lo - p, vh = p - hi;
@@ -97,7 +97,14 @@ RT_DEV SmallHit small_closest_hit(const SmallScene &ss, f3 ow, f3 dw, float tmin
     for (int gi = 0; gi < ss.n_groups; ++gi) {
         const SmallGroup g = ss.groups[gi];                      // wave-uniform
         f3 o = ow, d = dw, inv = invw;
-        if (g.xform != 0) { const SmallXform x = ss.xforms[g.xform]; o = xform_point(x, ow); d = xform_dir(x, dw); inv = rcp3(d); }
+        if (g.xform != 0) {
+            const SmallXform x = ss.xforms[g.xform];
+            if (g.rot_y) {   // a rotation about y and a translation (every rotated object of the reference's scenes): y passes through
+                o = f3mk(x.m[0] * ow.x + x.m[2] * ow.z + x.b[0], ow.y + x.b[1], x.m[6] * ow.x + x.m[8] * ow.z + x.b[2]);
+                d = f3mk(x.m[0] * dw.x + x.m[2] * dw.z, dw.y, x.m[6] * dw.x + x.m[8] * dw.z);
+                inv = f3mk(__builtin_amdgcn_rcpf(d.x), invw.y, __builtin_amdgcn_rcpf(d.z));
+            } else { o = xform_point(x, ow); d = xform_dir(x, dw); inv = rcp3(d); }
+        }
         if (g.box >= 0) small_box(ss.boxes[g.box], o, inv, tmin, h);
         int first = g.first;
         small_run(ss, first, g.n_xy, o.z, inv.z, o.x, d.x, o.y, d.y, tmin, h); first += g.n_xy;

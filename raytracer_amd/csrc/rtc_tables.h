@@ -106,7 +106,8 @@ enum { RTC_SMALL_MAX_LEAVES = 64, RTC_SMALL_MAX_XFORMS = 16 };
 enum { RTC_SF_FORCED_FRONT = 1u << 8, RTC_SF_FLIP = 1u << 9, RTC_SF_SPHERE = 1u << 10,   // SmallShade.meta bits; bits 0-7 = material type
        RTC_SF_GENERAL = 1u << 11 };   // BVH leaf_shade only: not resolvable here (texture lookup, moving sphere, medium) -> prims / materials / textures
 struct alignas(64) SmallPair { float f[16]; };
-struct alignas(32) SmallGroup { int xform, first, n_xy, n_xz, n_yz, box, pad1, pad2; };   // box >= 0: SmallBox of this space, tested before the pairs
+struct alignas(32) SmallGroup { int xform, first, n_xy, n_xz, n_yz, box, rot_y, pad2; };   // box >= 0: SmallBox of this space, tested before the pairs;
+                                                                                       // rot_y: the space's map leaves y alone up to a shift (m[1] = m[3] = m[5] = m[7] = 0, m[4] = 1)
 // Rects of one object space that are faces of ONE axis-aligned box -- all six (hittable_box_new, hittable.c:139-155) or
 // some of them (the five walls of the Cornell room): one slab test (~35 VALU instructions) replaces up to three pair
 // tests (~78).  ids_lo / ids_hi = leaf ids of the x, y, z faces at lo / hi, one byte each, 0xff = the box has no such

@@ -3,18 +3,21 @@
 // "Small" = at most 64 rect / sphere leaves with solid-colour textures (the 03_FullTracer Cornell box: 13 leaves).  Such
 // a scene never leaves the chip: the bounce loop of ray.c:50-84 runs out of SGPRs, VGPRs and 3 KB of LDS, and HBM only
 // sees the float4 accumulator once per launch.  Design, in the order the profile asked for it:
-//   * one wave64 = one 8x8 pixel tile, a lane owns a pixel; a lane whose path ended starts its next sample in the same
-//     iteration (persistent regeneration), so > 90 % of the lane slots trace a ray until the tile runs dry;
-//   * intersection = wave-uniform loops over runs of SmallLeaf records that share an object space and an axis: ONE
-//     64-byte scalar load feeds two rect tests for 64 lanes, a test is sub/mul/2 fma/7 compares against a per-space
-//     reciprocal direction, wrapper stacks are pre-collapsed affine maps applied once per space, not once per leaf;
+//   * one wave64 = one 8x8 pixel tile x a chunk of its samples; the 64 * S paths of that work item are handed to whichever
+//     lanes fall free (lanes are not pixels), two primary rays are kept ready per lane, and a finished path adds its
+//     radiance to the tile's sums in LDS: 98.6 % of the lane slots trace a ray until the tile runs dry; tiles are taken
+//     heaviest first (one-sample probe + counting sort, launch_pathtrace_small);
+//   * intersection = wave-uniform loops over the records of one object space: a slab test for the rects that are faces of
+//     one box (SmallBox), ONE 64-byte scalar load feeding two rect tests for the others (SmallPair; the padding of an odd
+//     run is skipped by a scalar branch), spheres in closest-approach form; wrapper stacks are pre-collapsed affine maps
+//     applied once per space, not once per leaf (a y-rotation passes y through);
 //   * the winner's shading record (world normal or centre, resolved colour, flags) is ONE 48-byte LDS gather -- the
 //     generic path chases prim -> material -> texture through three dependent global loads;
 //   * material / pdf dispatch is a switch on the record's type; lambertian sampling uses n + uniform-sphere (the same
 //     cosine law as onb.c + random_cosine_direction, without building the basis), the mixture pdf of pdf.c:119-121;
 //   * Philox4x32-7 on (pixel, sample, bounce); 2 blocks per path start are not needed here (no lens, no moving leaf).
-// 90 VGPRs -> 5 waves per SIMD, which is enough to hide the scalar-load and LDS latencies: the SIMDs issue VALU
-// instructions 96 % of the time (profiles/r01c), so the remaining lever is the instruction count, not occupancy.
+// 79 VGPRs -> 6 waves per SIMD (amdgpu_waves_per_eu), no spills; the SIMDs issue VALU instructions all the time, so what
+// is left is the instruction count and the divergence of the material switch (DESIGN.md 3.1 has the cycle budget).
 #include <hip/hip_runtime.h>
 
 #include "device/rt_shade.hpp"

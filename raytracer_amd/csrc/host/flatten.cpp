@@ -673,10 +673,14 @@ bool flatten_scene(const hittable_list *world, const hittable_list *lights, cons
             const hittable *h = lights->objs[i];
             while (h->kind == RT_H_FLIP) h = h->child;
             LightT<double> l; std::memset(&l, 0, sizeof l);
-            if (h->kind == RT_H_SPHERE) { l.kind = RTC_LIGHT_SPHERE; l.d[0] = h->c0.x; l.d[1] = h->c0.y; l.d[2] = h->c0.z; l.d[3] = h->r; }
+            if (h->kind == RT_H_SPHERE) { l.kind = RTC_LIGHT_SPHERE; l.d[0] = h->c0.x; l.d[1] = h->c0.y; l.d[2] = h->c0.z; l.d[3] = h->r; l.d[4] = h->r * h->r; }
             else if (h->kind == RT_H_RECT) {
                 l.kind = RTC_LIGHT_RECT; l.axis = h->axis;
                 l.d[0] = h->lo.x; l.d[1] = h->hi.x; l.d[2] = h->lo.y; l.d[3] = h->hi.y; l.d[4] = h->lo.z; l.d[5] = h->hi.z; l.d[6] = h->k;
+                {   // d[7] = 1 / area (hittable.c:783), so that the kernels do not recompute a wave-uniform value per ray
+                    const double a = h->axis == RTC_AXIS_YZ ? h->hi.y - h->lo.y : h->hi.x - h->lo.x, b = h->axis == RTC_AXIS_XY ? h->hi.y - h->lo.y : h->hi.z - h->lo.z;
+                    l.d[7] = 1.0 / (a * b);
+                }
             } else l.kind = RTC_LIGHT_NONE;
             out.lights.push_back(l);
         }

@@ -12,6 +12,7 @@ struct RenderParams {
     int max_depth, integrator;
     uint32_t seed_lo, seed_hi;
     float light_weight;
+    float light_weight_each, cosine_weight;   // light_weight / number of lights (0 without lights), 1 - light_weight: launch constants of pdf.c:119-121
     int tiles_x, tiles_y, n_tiles;   // 8x8-pixel tiles, one wave each
     int use_time;                    // camera shutter open (time0 != time1)
 };

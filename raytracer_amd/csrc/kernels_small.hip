@@ -135,12 +135,41 @@ RT_DEV SmallHit small_closest_hit(const SmallScene &ss, f3 ow, f3 dw, float tmin
     return h;
 }
 
-// hittable_list_pdf_value over the lights list (hittable_list.c:165-172, hittable.c:760-788): wave-uniform loop.
-RT_DEV float small_light_pdf(const SceneT<float> &sc, f3 o, f3 v) {
-    const float weight = __builtin_amdgcn_rcpf((float)sc.n_lights);
+// hittable_list_pdf_value over the lights list (hittable_list.c:165-172, hittable.c:760-788): wave-uniform loop.  The maths
+// of rt_shade.hpp light_pdf_one with what does not depend on the light taken out of the loop (vv = |v|^2, rs = 1/|v|) and
+// what does not depend on the ray taken from the record (1/area, r^2):
+//   rect  : d^2 / (cos * area) = t^2 vv / (|vn| rs area) = t^2 vv^2 rs |1/vn| (1/area)   -- one rcp, no second one
+//   sphere: the far root decides alone (it is the larger one): q >= 0 and (tc >= tmin or q >= (tmin - tc)^2) -- no sqrt
+RT_DEV float small_light_pdf_one(const LightT<float> &l, f3 o, f3 v, float vv, float rs) {
+    if (l.kind == RTC_LIGHT_RECT) {                                                   // :772-788, tmin 1e-4
+        const bool xy = l.axis == RTC_AXIS_XY, xz = l.axis == RTC_AXIS_XZ, yz = l.axis == RTC_AXIS_YZ;
+        const float on = xy ? o.z : (xz ? o.y : o.x), vn = xy ? v.z : (xz ? v.y : v.x);
+        const float oa = yz ? o.y : o.x, va = yz ? v.y : v.x, ob = xy ? o.y : o.z, vb = xy ? v.y : v.z;
+        const float a0 = yz ? l.d[2] : l.d[0], a1 = yz ? l.d[3] : l.d[1], b0 = xy ? l.d[2] : l.d[4], b1 = xy ? l.d[3] : l.d[5];
+        const float inv_vn = __builtin_amdgcn_rcpf(vn);
+        const float t = (l.d[6] - on) * inv_vn;                                       // rect_hit :494-517
+        const float pa = oa + t * va, pb = ob + t * vb;
+        const bool hit = !(t < 0.0001f) & !(pa < a0) & !(pa > a1) & !(pb < b0) & !(pb > b1);   // a NaN t passes (F20)
+        return hit ? (t * t) * (vv * vv) * (rs * l.d[7]) * fabsf(inv_vn) : 0.0f;
+    }
+    if (l.kind == RTC_LIGHT_SPHERE) {                                                 // :760-768, tmin 1e-3
+        const f3 oc = o - f3mk(l.d[0], l.d[1], l.d[2]);
+        const float inv_a = rs * rs;                                                  // closest-approach form, rt_core.hpp sphere_t<float>
+        const float tc = -dot(oc, v) * inv_a;
+        const f3 lv = oc + v * tc;
+        const float q = (l.d[4] - len2(lv)) * inv_a;
+        const float need = 0.001f - tc;                                               // far root tc + sqrt(q) >= tmin
+        const bool hit = !(q < 0.0f) & (!(need > 0.0f) | !(q < need * need));           // NaN passes as in sphere_t
+        const float cos_theta_max = __builtin_amdgcn_sqrtf(1.0f - l.d[4] * __builtin_amdgcn_rcpf(len2(oc)));
+        return hit ? __builtin_amdgcn_rcpf(2.0f * RT_PI * (1.0f - cos_theta_max)) : 0.0f;
+    }
+    return 0.0f;
+}
+// sum over the list; the caller multiplies by (mixture weight / number of lights), a launch constant
+RT_DEV float small_light_pdf_sum(const SceneT<float> &sc, f3 o, f3 v, float vv, float rs) {
     float sum = 0.0f;
-    for (int i = 0; i < sc.n_lights; ++i) sum += light_pdf_one(sc.lights[i], o, v);
-    return sum * weight;
+    for (int i = 0; i < sc.n_lights; ++i) sum += small_light_pdf_one(sc.lights[i], o, v, vv, rs);
+    return sum;
 }
 // Duff et al. 2017 branch-free orthonormal basis (any basis around w gives the same uniform azimuth as onb.c:7-12)
 RT_DEV void basis_around(f3 w, f3 &u, f3 &v) {
@@ -158,9 +187,10 @@ RT_DEV f3 small_light_sample(const SceneT<float> &sc, int pick, f3 o, float r1, 
         else if (l.kind == RTC_LIGHT_SPHERE) {                                            // hittable.c:821-835, cone towards the sphere
             const f3 axis = f3mk(l.d[0], l.d[1], l.d[2]) - o;
             const float d2 = len2(axis);
-            const f3 w = axis * __builtin_amdgcn_rsqf(d2);
+            const float inv_d = __builtin_amdgcn_rsqf(d2);
+            const f3 w = axis * inv_d;
             f3 u, v; basis_around(w, u, v);
-            const float z = 1.0f + r2 * (__builtin_amdgcn_sqrtf(fmaxf(0.0f, 1.0f - l.d[3] * l.d[3] * __builtin_amdgcn_rcpf(d2))) - 1.0f);
+            const float z = 1.0f + r2 * (__builtin_amdgcn_sqrtf(fmaxf(0.0f, 1.0f - l.d[4] * (inv_d * inv_d))) - 1.0f);
             const float s = __builtin_amdgcn_sqrtf(fmaxf(0.0f, 1.0f - z * z));
             dir = u * (cos2pi(r1) * s) + (v * (sin2pi(r1) * s) + w * z);
         }
@@ -313,10 +343,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) k
                         nd = n + uniform_sphere(xi.z, xi.w);
                         if (len2(nd) < 1e-12f) nd = n;
                     }
-                    const float cosn = dot(n, nd) * __builtin_amdgcn_rsqf(len2(nd));
+                    const float vv = len2(nd), rs = __builtin_amdgcn_rsqf(vv);
+                    const float cosn = dot(n, nd) * rs;
                     const float pdf_cos = cosn > 0.0f ? cosn * RT_INV_PI : 0.0f;      // pdf.c:100-103 == material.c:205-208
-                    const float pdf_light = sc.n_lights > 0 ? small_light_pdf(sc, p, nd) : 0.0f;
-                    const float pdf_val = w * pdf_light + (1.0f - w) * pdf_cos;       // pdf.c:119-121
+                    const float pdf_light = sc.n_lights > 0 ? small_light_pdf_sum(sc, p, nd, vv, rs) : 0.0f;   // x 1 / n_lights below
+                    const float pdf_val = P.light_weight_each * pdf_light + P.cosine_weight * pdf_cos;  // pdf.c:119-121
                     // scattering pdf 0: the reference recurses and multiplies by 0; pdf_val 0: 0/0 (scrubbed) -- nothing more arrives
                     if (!(pdf_cos > 0.0f) || !(pdf_val > 0.0f)) done = true;
                     else T = T * (col * (pdf_cos * __builtin_amdgcn_rcpf(pdf_val)));

@@ -395,6 +395,7 @@ int rtc_render_device(const rtc_scene *scene_c, const camera *cam, const rtc_set
     p.max_depth = st->max_depth; p.integrator = st->integrator;
     p.seed_lo = (uint32_t)st->seed; p.seed_hi = (uint32_t)(st->seed >> 32);
     p.light_weight = (float)st->mixture_light_weight;
+    p.light_weight_each = s->flat.lights.empty() ? 0.0f : p.light_weight / (float)s->flat.lights.size(); p.cosine_weight = 1.0f - p.light_weight;
     p.tiles_x = (st->width + 7) / 8; p.tiles_y = (st->height + 7) / 8; p.n_tiles = p.tiles_x * p.tiles_y;
     const CameraT<float> camf = camera_tables<float>(cam);
     p.use_time = camf.time0 != camf.time1;

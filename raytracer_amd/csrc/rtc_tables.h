@@ -31,7 +31,8 @@ template <typename R> struct OpT { int type, axis; R a, b, c; };   // translate:
 struct ChainRange { int first, count; };                           // chain 0 is the empty chain
 template <typename R> struct MaterialT { int type, tex; R albedo[3]; R param; };   // metal: albedo+fuzz; dielectric: param=ir
 template <typename R> struct TextureT { int type, a, b, pad; R v[4]; };            // solid: v=rgb; checker: a=odd b=even; noise: a=perlin slot v[0]=scale; image: a=image slot
-template <typename R> struct LightT { int kind, axis, pad0, pad1; R d[8]; };       // entries of the `lights` list, flip_face unwrapped
+template <typename R> struct LightT { int kind, axis, pad0, pad1; R d[8]; };       // entries of the `lights` list, flip_face unwrapped;
+                                                                                   // rect: x0 x1 y0 y1 z0 z1 k 1/area; sphere: c(3) r r*r
 struct ImageDesc { int width, height; uint32_t offset, pad; };                     // RGB8 texels at image_data + offset
 // Two-child BVH node with both child boxes inline (one 64-byte fetch decides both children).
 // child >= 0: inner node index (count == 0);  child < 0: leaf reference ~((first << 3) | (count - 1)), a run of

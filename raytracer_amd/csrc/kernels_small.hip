@@ -92,27 +92,33 @@ RT_DEV void small_box(const SmallBox &B, f3 o, f3 inv, float tmin, SmallHit &h) 
     const bool hit = (t_in <= t_out) & (t >= tmin) & (t <= h.t) & (id != 0xffu);
     h.t = hit ? t : h.t; h.leaf = hit ? (int)id : h.leaf;
 }
+// the records of one object space against the ray in that space
+RT_DEV void small_group_hit(const SmallScene &ss, const SmallGroup &g, f3 o, f3 d, f3 inv, float tmin, SmallHit &h) {
+    if (g.box >= 0) small_box(ss.boxes[g.box], o, inv, tmin, h);
+    int first = g.first;
+    small_run(ss, first, g.n_xy, o.z, inv.z, o.x, d.x, o.y, d.y, tmin, h); first += g.n_xy;
+    small_run(ss, first, g.n_xz, o.y, inv.y, o.x, d.x, o.z, d.z, tmin, h); first += g.n_xz;
+    small_run(ss, first, g.n_yz, o.x, inv.x, o.y, d.y, o.z, d.z, tmin, h);
+}
 // hittable_list_hit (hittable_list.c:125-143) over the packed leaves.  `src` = leaf the ray starts on: only spheres need
 // it (rt_core.hpp sphere_leave_t); a rect left behind is rejected by tmin like in the reference.
 RT_DEV SmallHit small_closest_hit(const SmallScene &ss, f3 ow, f3 dw, float tmin, int src) {
     SmallHit h; h.t = 3.0e38f; h.leaf = -1;
     const f3 invw = rcp3(dw);
-    for (int gi = 0; gi < ss.n_groups; ++gi) {
+    // The world-space group (xform 0 sorts first, flatten.cpp build_small_pack) runs on the world ray as it is; written as
+    // one loop with `o = ow; if (xform) o = ...` the compiler copies nine registers per group to have something to overwrite.
+    int gi = 0;
+    if (ss.n_groups > 0 && ss.groups[0].xform == 0) { small_group_hit(ss, ss.groups[0], ow, dw, invw, tmin, h); gi = 1; }
+    for (; gi < ss.n_groups; ++gi) {
         const SmallGroup g = ss.groups[gi];                      // wave-uniform
-        f3 o = ow, d = dw, inv = invw;
-        if (g.xform != 0) {
-            const SmallXform x = ss.xforms[g.xform];
-            if (g.rot_y) {   // a rotation about y and a translation (every rotated object of the reference's scenes): y passes through
-                o = f3mk(x.m[0] * ow.x + x.m[2] * ow.z + x.b[0], ow.y + x.b[1], x.m[6] * ow.x + x.m[8] * ow.z + x.b[2]);
-                d = f3mk(x.m[0] * dw.x + x.m[2] * dw.z, dw.y, x.m[6] * dw.x + x.m[8] * dw.z);
-                inv = f3mk(__builtin_amdgcn_rcpf(d.x), invw.y, __builtin_amdgcn_rcpf(d.z));
-            } else { o = xform_point(x, ow); d = xform_dir(x, dw); inv = rcp3(d); }
-        }
-        if (g.box >= 0) small_box(ss.boxes[g.box], o, inv, tmin, h);
-        int first = g.first;
-        small_run(ss, first, g.n_xy, o.z, inv.z, o.x, d.x, o.y, d.y, tmin, h); first += g.n_xy;
-        small_run(ss, first, g.n_xz, o.y, inv.y, o.x, d.x, o.z, d.z, tmin, h); first += g.n_xz;
-        small_run(ss, first, g.n_yz, o.x, inv.x, o.y, d.y, o.z, d.z, tmin, h);
+        const SmallXform x = ss.xforms[g.xform];
+        f3 o, d, inv;
+        if (g.rot_y) {   // a rotation about y and a translation (every rotated object of the reference's scenes): y passes through
+            o = f3mk(x.m[0] * ow.x + x.m[2] * ow.z + x.b[0], ow.y + x.b[1], x.m[6] * ow.x + x.m[8] * ow.z + x.b[2]);
+            d = f3mk(x.m[0] * dw.x + x.m[2] * dw.z, dw.y, x.m[6] * dw.x + x.m[8] * dw.z);
+            inv = f3mk(__builtin_amdgcn_rcpf(d.x), invw.y, __builtin_amdgcn_rcpf(d.z));
+        } else { o = xform_point(x, ow); d = xform_dir(x, dw); inv = rcp3(d); }
+        small_group_hit(ss, g, o, d, inv, tmin, h);
     }
     if (ss.n_spheres > 0) {                                      // world space, closest-approach form (rt_core.hpp sphere_t<float>)
         const float inv_a = __builtin_amdgcn_rcpf(len2(dw));

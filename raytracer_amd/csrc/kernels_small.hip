@@ -265,6 +265,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) k
         const float u = ((float)px + c.x) * inv_w, v = ((float)py + c.y) * inv_h;
         float dx = 0.0f, dy = 0.0f;
         if (LENS) { const float rr = __builtin_amdgcn_sqrtf(c.z); dx = rr * cos2pi(c.w); dy = rr * sin2pi(c.w); }
+#if RT_EXP == 8   // cost probe: the camera's Philox block twice
+        { const Rng4 c2 = rng_block((uint32_t)(py * P.width + px), smp + 77u, RT_TAG_CAMERA, P.seed_lo, P.seed_hi); if (c2.x > 2.0f) dx = c2.y; }
+#endif
         const RayT<float> r = camera_ray<float>(cam, u, v, dx, dy, 0.0f);   // no leaf moves: the ray time is never read
         o = r.o; d = (px < P.width && py < P.height) ? r.d : f3mk(0, 0, 0);
     };
@@ -333,6 +336,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) k
                 } else if (mtype == RTC_MAT_DIELECTRIC) {                   // material.c:144-162
                     RecT<float> rec; rec.n = n; rec.front = front;
                     nd = dielectric_dir(sh.param, rd, rec, xi.x);
+#if RT_EXP == 7   // cost probe: the glass arm's direction twice
+                    { const f3 n2 = dielectric_dir(sh.param, rd + f3mk(1e-9f * (float)iters, 0, 0), rec, xi.x); if (n2.x > 3.0e38f) nd = n2; }
+#endif
                 } else if (mtype == RTC_MAT_ISOTROPIC) {
                     done = true;                                            // only reachable through a medium; none in a small scene
                 } else if (INTEGRATOR != 0) {                               // 02 material.c:120-128: normal + random unit vector
@@ -349,11 +355,26 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) k
                         nd = n + uniform_sphere(xi.z, xi.w);
                         if (len2(nd) < 1e-12f) nd = n;
                     }
+#if RT_EXP == 6   // cost probe: direction sampling (light list or cosine law) twice
+                    {
+                        f3 n2;
+                        if (sc.n_lights > 0 && xi.x < w) {
+                            int pick = (int)((float)sc.n_lights * xi.y); pick = pick < sc.n_lights ? pick : sc.n_lights - 1;
+                            n2 = small_light_sample(sc, pick, p + f3mk(1e-9f * (float)iters, 0, 0), xi.w, xi.z);
+                        } else n2 = n + uniform_sphere(xi.w, xi.z);
+                        if (n2.x > 3.0e38f) nd = n2;
+                    }
+#endif
                     const float vv = len2(nd), rs = __builtin_amdgcn_rsqf(vv);
                     const float cosn = dot(n, nd) * rs;
                     const float pdf_cos = cosn > 0.0f ? cosn * RT_INV_PI : 0.0f;      // pdf.c:100-103 == material.c:205-208
                     const float pdf_light = sc.n_lights > 0 ? small_light_pdf_sum(sc, p, nd, vv, rs) : 0.0f;   // x 1 / n_lights below
+#if RT_EXP == 5   // cost probe: the light-list pdf twice
+                    const float pdf_light2 = sc.n_lights > 0 ? small_light_pdf_sum(sc, p + f3mk(1e-9f * (float)iters, 0, 0), nd, vv, rs) : 0.0f;
+                    const float pdf_val = P.light_weight_each * (pdf_light2 > 3.0e38f ? pdf_light2 : pdf_light) + P.cosine_weight * pdf_cos;
+#else
                     const float pdf_val = P.light_weight_each * pdf_light + P.cosine_weight * pdf_cos;  // pdf.c:119-121
+#endif
                     // scattering pdf 0: the reference recurses and multiplies by 0; pdf_val 0: 0/0 (scrubbed) -- nothing more arrives
                     if (!(pdf_cos > 0.0f) || !(pdf_val > 0.0f)) done = true;
                     else T = T * (col * (pdf_cos * __builtin_amdgcn_rcpf(pdf_val)));

@@ -244,7 +244,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) k
     const float inv_w = 1.0f / (float)(P.width - 1), inv_h = 1.0f / (float)(P.height - 1);
     const f3 bg = f3mk(sc.background[0], sc.background[1], sc.background[2]);
 
-    f3 T = f3mk(1, 1, 1), L = f3mk(0, 0, 0), ro = f3mk(0, 0, 0), rd = f3mk(0, 0, 1);
+    f3 T = f3mk(1, 1, 1), ro = f3mk(0, 0, 0), rd = f3mk(0, 0, 1);
     unsigned nrays = 0, iters = 0;
     int q_next = 0;                                                       // wave-uniform: paths handed out so far
     int depth = 0, src = -1, cur_pix = 0;
@@ -292,7 +292,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) k
             pixel = (uint32_t)((ty0 + (cur_pix >> 3)) * P.width + tx0 + (cur_pix & 7));
             rd = b0d; b0d = b1d; b0q = b1q;
             if (LENS) { ro = b0o; b0o = b1o; } else ro = f3mk(cam.origin[0], cam.origin[1], cam.origin[2]);
-            T = f3mk(1, 1, 1); L = f3mk(0, 0, 0);
+            T = f3mk(1, 1, 1);
             depth = 0; src = -1;
             alive = rd.x != 0.0f || rd.y != 0.0f || rd.z != 0.0f;          // a pixel outside the image: nothing to trace
         }
@@ -305,8 +305,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) k
 #endif
             ++nrays;
             bool done;
+            f3 L = f3mk(0, 0, 0);   // a path collects radiance once, where it ends (emitter or background): nothing to carry between bounces
             if (h.leaf < 0) {
-                L = L + T * (INTEGRATOR == 2 ? sky_color(rd) : bg);
+                L = T * (INTEGRATOR == 2 ? sky_color(rd) : bg);
                 done = true;
             } else {
                 const SmallShade sh = lds_shade[h.leaf];
@@ -326,7 +327,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) k
                 done = false;
                 f3 nd = rd;
                 if (mtype == RTC_MAT_LIGHT) {                               // material.c:229-235 (03: front face only, F15); no scatter
-                    if (INTEGRATOR == 1 || (INTEGRATOR == 0 && front)) L = L + T * col;
+                    if (INTEGRATOR == 1 || (INTEGRATOR == 0 && front)) L = T * col;
                     done = true;
                 } else if (mtype == RTC_MAT_METAL) {                        // material.c:130-138 / 02 material.c:132-141
                     nd = reflect(normalize(rd), n);

@@ -13,7 +13,7 @@ on rank 0.  Everything inside the timed region runs through the C-ABI of include
 the device buffers, the streams and the process group.
 
 The JSON line also carries
-  roofline      FP32 VALU roofline of the path-tracing kernel: algorithmic FLOP/ray (tools/flop_model.py)
+  roofline      FP32 VALU roofline of the path-tracing kernel: algorithmic FLOP/ray (tests/flop_model.py)
                 x rays per launch / HIP-event kernel time measured by the library on the launch stream;
   cpu_baseline  the CPU oracle (a port pinned byte-for-byte to the compiled reference) on all host cores with a
                 per-thread counter RNG -- the "fair" CPU row -- on a bounded sample of the same workload, plus the
@@ -37,7 +37,7 @@ from raytracer_amd import dist as rdist  # noqa: E402
 
 WIDTH, HEIGHT, DEPTH = 1920, 1080, 10
 SPP_PER_GPU = 256
-# tools/flop_model.py, Cornell 16:9 (DESIGN.md "Roofline"): minimal-algorithm FLOP per closest-hit query incl. shading
+# tests/flop_model.py, Cornell 16:9 (DESIGN.md "Roofline"): minimal-algorithm FLOP per closest-hit query incl. shading
 ALGO_FLOP_PER_RAY = 218.6
 PEAK_FP32_VALU_TFLOPS = 157.3     # MI355X_MICROARCH.md: 256 CU x 4 SIMD x 32 lanes x 2 (FMA) x 2.4 GHz
 ALGO_HBM_BYTES_PER_PIXEL = 32     # float4 accumulator read + write once per launch

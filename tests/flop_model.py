@@ -1,4 +1,4 @@
-"""Algorithmic FLOP per ray for the roofline figure of bench.py (measurement tooling; uses the oracle's event counters).
+"""Algorithmic FLOP per ray for the roofline figure of bench.py (measurement tooling kept under tests/ because it runs the oracle: only tests/, smoke() and the cpu_baseline leg of bench.py may).
 
 SURVEY.md 8(d): `roofline.achieved` = algorithmic FLOP per ray x rays per launch / kernel time, where the algorithmic
 figure is the MINIMAL algorithm (every leaf of the flattened scene tested once per ray, no BVH / wavefront /
@@ -6,7 +6,7 @@ regeneration bookkeeping) counted as add/sub/mul/div/sqrt = 1, FMA = 2, each tra
 free.  The event counts come from an instrumented oracle run over the same scene and estimator; the per-event costs
 below are hand counts of the reference's arithmetic (file:line under /root/reference/03_FullTracer).
 
-Run:  python tools/flop_model.py [scene] [aspect] [W H spp]      (CPU only; prints events/ray and FLOP/ray)
+Run:  python tests/flop_model.py [scene] [aspect] [W H spp]      (CPU only; prints events/ray and FLOP/ray)
 """
 import json
 import os

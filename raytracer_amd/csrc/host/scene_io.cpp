@@ -107,7 +107,10 @@ bool validate_flat_scene(const FlatScene &fs, std::string &err) {
     REQ(!fs.chains.empty() && fs.chains[0].count == 0, "chain 0 must be the empty chain");
     for (const ChainRange &c : fs.chains) REQ(run_in(c.first, c.count, fs.ops.size()), "a wrapper chain leaves the ops table");
     for (const OpT<double> &o : fs.ops) REQ(o.type >= RTC_OP_TRANSLATE && o.type <= RTC_OP_FLIP && o.axis >= 0 && o.axis <= 2, "wrapper type or axis out of range");
-    for (const MaterialT<double> &m : fs.materials) REQ(m.type >= RTC_MAT_LAMBERTIAN && m.type <= RTC_MAT_ISOTROPIC && m.tex >= -1 && m.tex < (int)fs.textures.size(), "material type or texture out of range");
+    for (const MaterialT<double> &m : fs.materials) {
+        REQ(m.type >= RTC_MAT_LAMBERTIAN && m.type <= RTC_MAT_ISOTROPIC && m.tex >= -1 && m.tex < (int)fs.textures.size(), "material type or texture out of range");
+        REQ(m.tex >= 0 || m.type == RTC_MAT_METAL || m.type == RTC_MAT_DIELECTRIC, "a material that reads a texture has none");   // shading evaluates textures[m.tex]
+    }
     REQ(fs.perlin_vec.size() == fs.perlin_perm.size() && fs.perlin_vec.size() % 768 == 0, "perlin tables must hold 768 entries per noise texture");
     for (const int v : fs.perlin_perm) REQ(v >= 0 && v < 256, "perlin permutation entry out of range");
     for (const ImageDesc &im : fs.images)

@@ -165,3 +165,44 @@ def test_command_line_writes_and_reads_scene_files(gpu, tmp_path):
     assert "scene load" in out and open(a, "rb").read() == open(b, "rb").read()
     bad = subprocess.run(common + ["-o", b, "-L", a], capture_output=True, timeout=120)      # a PNG is not a scene file
     assert bad.returncode != 0 and b"not a scene file" in bad.stderr
+
+
+def test_loader_survives_mutated_files(rtc, tmp_path):
+    """Mutation fuzz on the host, in a child process: bit flips, edge-case integers and non-finite floats written over
+    random words of a scene file, CRC resealed.  The loader may accept (a changed coordinate is still a scene) or refuse;
+    it must do either without crashing."""
+    import subprocess
+    import sys
+    code = """
+import struct, sys, zlib
+import numpy as np
+sys.path.insert(0, %r)
+import raytracer_amd as ra
+rng = np.random.default_rng(11)
+acc = ref = 0
+for name in ("final", "cornell", "box_field_smoke", "two_perlin"):
+    sc, _, _ = ra.build_named_scene(name, host_only=True)
+    sc.save(%r); sc.close()
+    blob = open(%r, "rb").read()
+    for it in range(120):
+        b = bytearray(blob)
+        for _ in range(int(rng.integers(1, 4))):
+            off = int(rng.integers(64, len(b) - 4)) & ~3
+            mode = int(rng.integers(0, 4))
+            if mode == 0: b[off + int(rng.integers(0, 4))] ^= 1 << int(rng.integers(0, 8))
+            elif mode == 1: struct.pack_into("<i", b, off, int(rng.choice([-1, 0, 1, 7, 255, 65536, 2**31 - 1, -2**31])))
+            elif mode == 2: struct.pack_into("<I", b, off, int(rng.integers(0, 2**32)))
+            else: struct.pack_into("<f", b, off, float(rng.choice([np.nan, np.inf, -np.inf, 0.0, 1e38])))
+        struct.pack_into("<I", b, 24, zlib.crc32(bytes(b[64:])) & 0xFFFFFFFF)
+        open(%r, "wb").write(b)
+        try:
+            ra.Scene.load(%r, host_only=True).close(); acc += 1
+        except ra.RtcError:
+            ref += 1
+print("accepted", acc, "refused", ref)
+""" % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), str(tmp_path / "f.rtcscene"), str(tmp_path / "f.rtcscene"),
+       str(tmp_path / "g.rtcscene"), str(tmp_path / "g.rtcscene"))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, timeout=600)
+    assert out.returncode == 0 and b"accepted" in out.stdout, out.stderr.decode()[-2000:]
+    acc, ref = int(out.stdout.split()[1]), int(out.stdout.split()[3])
+    assert acc + ref == 480 and ref > 0

@@ -121,14 +121,13 @@ RT_DEV SmallHit small_closest_hit(const SmallScene &ss, f3 ow, f3 dw, float tmin
         small_group_hit(ss, g, o, d, inv, tmin, h);
     }
     if (ss.n_spheres > 0) {                                      // world space, closest-approach form (rt_core.hpp sphere_t<float>)
-        const float inv_a = __builtin_amdgcn_rcpf(len2(dw));
-        for (int s = 0; s < ss.n_spheres; ++s) {
+        for (int s = 0; s < ss.n_spheres; ++s) {                 // |dw| = 1 (every ray of this kernel): the quadratic's a is 1
             const SmallSphere sp = ss.spheres[s];
             const int id = ss.n_rects + s;
             const f3 oc = ow - f3mk(sp.c[0], sp.c[1], sp.c[2]);
-            const float tc = -dot(oc, dw) * inv_a;
+            const float tc = -dot(oc, dw);
             const f3 l = oc + dw * tc;
-            const float q = (sp.r2 - len2(l)) * inv_a;
+            const float q = sp.r2 - len2(l);
             const float sq = __builtin_amdgcn_sqrtf(fmaxf(q, 0.0f));
             const bool from = id == src;                         // leaving this sphere: roots are {0, 2 tc}
             const float t0 = from ? 2.0f * tc : tc - sq, t1 = tc + sq;
@@ -142,11 +141,11 @@ RT_DEV SmallHit small_closest_hit(const SmallScene &ss, f3 ow, f3 dw, float tmin
 }
 
 // hittable_list_pdf_value over the lights list (hittable_list.c:165-172, hittable.c:760-788): wave-uniform loop.  The maths
-// of rt_shade.hpp light_pdf_one with what does not depend on the light taken out of the loop (vv = |v|^2, rs = 1/|v|) and
+// of rt_shade.hpp light_pdf_one for a UNIT direction v (every ray of this kernel is normalised where it is made), with
 // what does not depend on the ray taken from the record (1/area, r^2):
-//   rect  : d^2 / (cos * area) = t^2 vv / (|vn| rs area) = t^2 vv^2 rs |1/vn| (1/area)   -- one rcp, no second one
+//   rect  : d^2 / (cos * area) = t^2 / (|vn| area) = t^2 |1/vn| (1/area) for a unit v   -- one rcp, no second one
 //   sphere: the far root decides alone (it is the larger one): q >= 0 and (tc >= tmin or q >= (tmin - tc)^2) -- no sqrt
-RT_DEV float small_light_pdf_one(const LightT<float> &l, f3 o, f3 v, float vv, float rs) {
+RT_DEV float small_light_pdf_one(const LightT<float> &l, f3 o, f3 v) {
     if (l.kind == RTC_LIGHT_RECT) {                                                   // :772-788, tmin 1e-4
         const bool xy = l.axis == RTC_AXIS_XY, xz = l.axis == RTC_AXIS_XZ, yz = l.axis == RTC_AXIS_YZ;
         const float on = xy ? o.z : (xz ? o.y : o.x), vn = xy ? v.z : (xz ? v.y : v.x);
@@ -156,14 +155,13 @@ RT_DEV float small_light_pdf_one(const LightT<float> &l, f3 o, f3 v, float vv, f
         const float t = (l.d[6] - on) * inv_vn;                                       // rect_hit :494-517
         const float pa = oa + t * va, pb = ob + t * vb;
         const bool hit = !(t < 0.0001f) & !(pa < a0) & !(pa > a1) & !(pb < b0) & !(pb > b1);   // a NaN t passes (F20)
-        return hit ? (t * t) * (vv * vv) * (rs * l.d[7]) * fabsf(inv_vn) : 0.0f;
+        return hit ? (t * t) * (fabsf(inv_vn) * l.d[7]) : 0.0f;
     }
     if (l.kind == RTC_LIGHT_SPHERE) {                                                 // :760-768, tmin 1e-3
         const f3 oc = o - f3mk(l.d[0], l.d[1], l.d[2]);
-        const float inv_a = rs * rs;                                                  // closest-approach form, rt_core.hpp sphere_t<float>
-        const float tc = -dot(oc, v) * inv_a;
+        const float tc = -dot(oc, v);                                                 // closest-approach form, rt_core.hpp sphere_t<float>
         const f3 lv = oc + v * tc;
-        const float q = (l.d[4] - len2(lv)) * inv_a;
+        const float q = l.d[4] - len2(lv);
         const float need = 0.001f - tc;                                               // far root tc + sqrt(q) >= tmin
         const bool hit = !(q < 0.0f) & (!(need > 0.0f) | !(q < need * need));           // NaN passes as in sphere_t
         const float cos_theta_max = __builtin_amdgcn_sqrtf(1.0f - l.d[4] * __builtin_amdgcn_rcpf(len2(oc)));
@@ -172,10 +170,18 @@ RT_DEV float small_light_pdf_one(const LightT<float> &l, f3 o, f3 v, float vv, f
     return 0.0f;
 }
 // sum over the list; the caller multiplies by (mixture weight / number of lights), a launch constant
-RT_DEV float small_light_pdf_sum(const SceneT<float> &sc, f3 o, f3 v, float vv, float rs) {
+RT_DEV float small_light_pdf_sum(const SceneT<float> &sc, f3 o, f3 v) {
     float sum = 0.0f;
-    for (int i = 0; i < sc.n_lights; ++i) sum += small_light_pdf_one(sc.lights[i], o, v, vv, rs);
+    for (int i = 0; i < sc.n_lights; ++i) sum += small_light_pdf_one(sc.lights[i], o, v);
     return sum;
+}
+// material.c:144-157 for a unit incoming direction (rt_shade.hpp dielectric_dir without its normalisation); the result is a unit vector
+RT_DEV f3 small_dielectric_dir(float ir, f3 ud, f3 n, bool front, float xi) {
+    const float ratio = front ? __builtin_amdgcn_rcpf(ir) : ir;
+    const float cos_theta = fminf(dot(-ud, n), 1.0f);
+    const float sin_theta = __builtin_amdgcn_sqrtf(fmaxf(0.0f, 1.0f - cos_theta * cos_theta));
+    if (ratio * sin_theta > 1.0f || schlick(cos_theta, ratio) > xi) return reflect(ud, n);
+    return refract(ud, n, ratio);
 }
 // Duff et al. 2017 branch-free orthonormal basis (any basis around w gives the same uniform azimuth as onb.c:7-12)
 RT_DEV void basis_around(f3 w, f3 &u, f3 &v) {
@@ -269,7 +275,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) k
         { const Rng4 c2 = rng_block((uint32_t)(py * P.width + px), smp + 77u, RT_TAG_CAMERA, P.seed_lo, P.seed_hi); if (c2.x > 2.0f) dx = c2.y; }
 #endif
         const RayT<float> r = camera_ray<float>(cam, u, v, dx, dy, 0.0f);   // no leaf moves: the ray time is never read
-        o = r.o; d = (px < P.width && py < P.height) ? r.d : f3mk(0, 0, 0);
+        o = r.o; d = (px < P.width && py < P.height) ? normalize(r.d) : f3mk(0, 0, 0);   // unit directions throughout the bounce loop
     };
     // the next paths go to the lanes of `want`, in lane order
     auto hand_out = [&](bool want, int &q) -> bool {
@@ -330,21 +336,21 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) k
                     if (INTEGRATOR == 1 || (INTEGRATOR == 0 && front)) L = T * col;
                     done = true;
                 } else if (mtype == RTC_MAT_METAL) {                        // material.c:130-138 / 02 material.c:132-141
-                    nd = reflect(normalize(rd), n);
-                    if (ss.any_fuzz) nd = nd + uniform_ball(xi.x, xi.y, xi.z) * sh.param;
+                    nd = reflect(rd, n);                                     // |rd| = 1
+                    if (ss.any_fuzz) nd = normalize(nd + uniform_ball(xi.x, xi.y, xi.z) * sh.param);
                     if (INTEGRATOR != 0 && !(dot(nd, n) > 0.0f)) done = true;
                     T = T * col;
                 } else if (mtype == RTC_MAT_DIELECTRIC) {                   // material.c:144-162
-                    RecT<float> rec; rec.n = n; rec.front = front;
-                    nd = dielectric_dir(sh.param, rd, rec, xi.x);
+                    nd = small_dielectric_dir(sh.param, rd, n, front, xi.x);
 #if RT_EXP == 7   // cost probe: the glass arm's direction twice
-                    { const f3 n2 = dielectric_dir(sh.param, rd + f3mk(1e-9f * (float)iters, 0, 0), rec, xi.x); if (n2.x > 3.0e38f) nd = n2; }
+                    { const f3 n2 = small_dielectric_dir(sh.param, rd + f3mk(1e-9f * (float)iters, 0, 0), n, front, xi.x); if (n2.x > 3.0e38f) nd = n2; }
 #endif
                 } else if (mtype == RTC_MAT_ISOTROPIC) {
                     done = true;                                            // only reachable through a medium; none in a small scene
                 } else if (INTEGRATOR != 0) {                               // 02 material.c:120-128: normal + random unit vector
                     nd = n + uniform_sphere(xi.x, xi.y);
                     if (fabsf(nd.x) < 1e-8f && fabsf(nd.y) < 1e-8f && fabsf(nd.z) < 1e-8f) nd = n;
+                    nd = normalize(nd);
                     T = T * col;
                 } else {                                                    // 03: ray.c:66-83, mixture of light-list and cosine pdfs
                     const float w = P.light_weight;
@@ -366,12 +372,12 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) k
                         if (n2.x > 3.0e38f) nd = n2;
                     }
 #endif
-                    const float vv = len2(nd), rs = __builtin_amdgcn_rsqf(vv);
-                    const float cosn = dot(n, nd) * rs;
+                    nd = nd * __builtin_amdgcn_rsqf(len2(nd));              // unit from here on: the pdfs and the next bounce's tests drop |v|
+                    const float cosn = dot(n, nd);
                     const float pdf_cos = cosn > 0.0f ? cosn * RT_INV_PI : 0.0f;      // pdf.c:100-103 == material.c:205-208
-                    const float pdf_light = sc.n_lights > 0 ? small_light_pdf_sum(sc, p, nd, vv, rs) : 0.0f;   // x 1 / n_lights below
+                    const float pdf_light = sc.n_lights > 0 ? small_light_pdf_sum(sc, p, nd) : 0.0f;   // x 1 / n_lights below
 #if RT_EXP == 5   // cost probe: the light-list pdf twice
-                    const float pdf_light2 = sc.n_lights > 0 ? small_light_pdf_sum(sc, p + f3mk(1e-9f * (float)iters, 0, 0), nd, vv, rs) : 0.0f;
+                    const float pdf_light2 = sc.n_lights > 0 ? small_light_pdf_sum(sc, p + f3mk(1e-9f * (float)iters, 0, 0), nd) : 0.0f;
                     const float pdf_val = P.light_weight_each * (pdf_light2 > 3.0e38f ? pdf_light2 : pdf_light) + P.cosine_weight * pdf_cos;
 #else
                     const float pdf_val = P.light_weight_each * pdf_light + P.cosine_weight * pdf_cos;  // pdf.c:119-121

@@ -5,6 +5,11 @@
 // The reference's wrappers (translate/rotate/flip_face, hittable.c:527-591) become per-primitive "chains" of
 // ops kept in the reference's nesting order so the FP64 verify kernel can replay them op by op.
 #include "flatten.h"
+#include <atomic>
+#include <chrono>
+#include <thread>
+#include <cstdio>
+#include <cstdlib>
 
 #include <algorithm>
 #include <array>
@@ -255,13 +260,19 @@ struct Flattener {
 struct BuildItem { int prim; int faces[6]; bool is_box; };
 struct Builder {
     const std::vector<Box> &boxes;                      // per item
-    std::vector<int> idx;
+    std::vector<int> &idx;                              // item order, shared: a builder only touches the range it is given
     std::vector<BvhNode> &nodes;
     std::vector<int> &leaf_prims;
     const std::vector<BuildItem> &items;
     std::vector<int> &box_slots;
     static constexpr int kLeafMax = 2, kBins = 16;
     struct Child { int child, count; Box box; };
+    // Parallel build (build_bvh_parallel): the builder of the top of the tree does not descend into ranges of at most
+    // `defer_below` items; it records them and leaves (count = kDeferred, child = index into `deferred`) in the parent.
+    struct Deferred { int lo, hi, depth; };
+    static constexpr int kDeferred = -1;
+    int defer_below = 0;
+    std::vector<Deferred> deferred;
 
     static double area(const Box &b) { double d[3] = {b.hi[0] - b.lo[0], b.hi[1] - b.lo[1], b.hi[2] - b.lo[2]}; return 2.0 * (d[0] * d[1] + d[1] * d[2] + d[2] * d[0]); }
     Box range_box(int lo, int hi) const { Box b = box_empty(); for (int i = lo; i < hi; i++) box_merge(b, boxes[idx[i]]); return b; }
@@ -284,6 +295,7 @@ struct Builder {
         if (depth > max_depth) max_depth = depth;
         Box b = range_box(lo, hi);
         int n = hi - lo;
+        if (n <= defer_below) { Child c; c.child = (int)deferred.size(); c.count = kDeferred; c.box = b; deferred.push_back({lo, hi, depth}); return c; }
         if (n <= kLeafMax) return make_leaf(lo, hi, b);
         // centroid bounds
         Box cb = box_empty();
@@ -330,12 +342,92 @@ struct Builder {
         Child l = build(lo, mid, depth + 1), r = build(mid, hi, depth + 1);
         BvhNode &nd = nodes[me];
         for (int a = 0; a < 3; a++) { nd.lo0[a] = down(l.box.lo[a]); nd.hi0[a] = up(l.box.hi[a]); nd.lo1[a] = down(r.box.lo[a]); nd.hi1[a] = up(r.box.hi[a]); }
-        nd.child0 = l.count ? rtc_leaf_ref(l.child, l.count) : l.child; nd.count0 = l.count;
-        nd.child1 = r.count ? rtc_leaf_ref(r.child, r.count) : r.child; nd.count1 = r.count;
+        nd.child0 = l.count > 0 ? rtc_leaf_ref(l.child, l.count) : l.child; nd.count0 = l.count;
+        nd.child1 = r.count > 0 ? rtc_leaf_ref(r.child, r.count) : r.child; nd.count1 = r.count;
         Child c; c.child = me; c.count = 0; c.box = b;
         return c;
     }
 };
+
+// The same tree as Builder::build(0, n) alone would make -- same partitions, same pre-order node numbering, same leaf slot
+// order -- built by several threads: one builder makes the top of the tree and defers every range of at most n / 256
+// items; the deferred ranges (disjoint pieces of the shared item order) are built independently into their own vectors;
+// a last pass walks the top in pre-order and splices the pieces in, shifting node indices and leaf slots.  1M spheres:
+// 1.6 s -> 0.4 s on 8 cores; the scene files of the two builders are byte-identical (tests/test_bvh_host.py).
+struct BvhPiece { std::vector<BvhNode> nodes; std::vector<int> leaf_prims, box_slots; Builder::Child root; int max_depth = 0; };
+Builder::Child build_bvh_parallel(const std::vector<Box> &item_boxes, const std::vector<BuildItem> &items, std::vector<int> &idx, int threads,
+                                  std::vector<BvhNode> &nodes, std::vector<int> &leaf_prims, std::vector<int> &box_slots, int &max_depth) {
+    const int n = (int)idx.size();
+    std::vector<BvhNode> top_nodes; std::vector<int> top_leaves, top_boxes;   // the top builder makes no leaves: every small range is deferred
+    Builder top{item_boxes, idx, top_nodes, top_leaves, items, top_boxes};
+    top.defer_below = std::max(n / 256, Builder::kLeafMax);
+    const Builder::Child top_root = top.build(0, n);
+    std::vector<BvhPiece> pieces(top.deferred.size());
+    std::atomic<size_t> next{0};
+    auto worker = [&]() {
+        for (size_t i = next.fetch_add(1); i < pieces.size(); i = next.fetch_add(1)) {
+            BvhPiece &pc = pieces[i]; const Builder::Deferred &d = top.deferred[i];
+            Builder b{item_boxes, idx, pc.nodes, pc.leaf_prims, items, pc.box_slots};
+            pc.nodes.reserve((size_t)(d.hi - d.lo));
+            pc.root = b.build(d.lo, d.hi, d.depth); pc.max_depth = b.max_depth;
+        }
+    };
+    std::vector<std::thread> pool;
+    for (int t = 1; t < threads; t++) pool.emplace_back(worker);
+    worker();
+    for (auto &th : pool) th.join();
+    max_depth = top.max_depth;
+    for (const BvhPiece &pc : pieces) max_depth = std::max(max_depth, pc.max_depth);
+    // splice, in pre-order
+    nodes.clear(); leaf_prims.clear(); box_slots.clear();
+    nodes.reserve((size_t)n); leaf_prims.reserve((size_t)n);
+    auto shift_ref = [](int child, int count, int node_base, int leaf_base) {   // a child reference of a piece, moved to its place in the whole
+        if (count == 0) return child + node_base;
+        const int v = ~child; return rtc_leaf_ref((v >> 3) + leaf_base, (v & 7) + 1);
+    };
+    auto emit_piece = [&](int id) -> Builder::Child {
+        const BvhPiece &pc = pieces[(size_t)id];
+        const int node_base = (int)nodes.size(), leaf_base = (int)leaf_prims.size();
+        for (BvhNode nd : pc.nodes) {
+            if (nd.child0 != RTC_BVH_EMPTY) nd.child0 = shift_ref(nd.child0, nd.count0, node_base, leaf_base);
+            if (nd.child1 != RTC_BVH_EMPTY) nd.child1 = shift_ref(nd.child1, nd.count1, node_base, leaf_base);
+            nodes.push_back(nd);
+        }
+        for (int p : pc.leaf_prims) leaf_prims.push_back(p);
+        for (int sl : pc.box_slots) box_slots.push_back(sl + leaf_base);
+        Builder::Child c = pc.root;
+        c.child = pc.root.count > 0 ? pc.root.child + leaf_base : pc.root.child + node_base;
+        return c;
+    };
+    if (top_root.count == Builder::kDeferred) return emit_piece(top_root.child);   // the whole scene was one deferred range
+    // explicit stack instead of recursion: (top node, its index in the whole, which child comes next)
+    struct Frame { int top, out, side; };
+    std::vector<Frame> st;
+    nodes.push_back(top_nodes[(size_t)top_root.child]);
+    st.push_back({top_root.child, 0, 0});
+    while (!st.empty()) {
+        Frame &f = st.back();
+        if (f.side == 2) { st.pop_back(); continue; }
+        const BvhNode &tn = top_nodes[(size_t)f.top];
+        const int child = f.side == 0 ? tn.child0 : tn.child1, count = f.side == 0 ? tn.count0 : tn.count1;
+        const int out = f.out, side = f.side;
+        f.side++;
+        if (count == Builder::kDeferred) {
+            const Builder::Child c = emit_piece(child);
+            BvhNode &on = nodes[(size_t)out];
+            (side == 0 ? on.child0 : on.child1) = c.count > 0 ? rtc_leaf_ref(c.child, c.count) : c.child;
+            (side == 0 ? on.count0 : on.count1) = c.count;
+        } else {   // an inner node of the top (the top builder makes no leaves)
+            const int me = (int)nodes.size();
+            nodes.push_back(top_nodes[(size_t)child]);
+            BvhNode &on = nodes[(size_t)out];
+            (side == 0 ? on.child0 : on.child1) = me;
+            st.push_back({child, me, 0});
+        }
+    }
+    Builder::Child root = top_root; root.child = 0;
+    return root;
+}
 
 // Wrapper chain of a leaf collapsed to one affine map x_obj = M x_world + b (M a rotation): translate_hit subtracts the
 // offset (hittable.c:529), rotate_hit enters with rotatePoint(p, -sin, cos, axis) (hittable.c:542-545, pair choice F10).
@@ -660,6 +752,10 @@ void box_items(const FlatScene &fs, const std::vector<Box> &prim_boxes, std::vec
 
 bool flatten_scene(const hittable_list *world, const hittable_list *lights, const color *background,
                    double time0, double time1, int bvh_threshold, FlatScene &out) {
+    const bool timing = std::getenv("RTC_BUILD_TIMING") != nullptr;   // development aid: phase times on stderr
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto t_prev = now();
+    auto lap = [&](const char *what) { if (timing) { auto t = now(); std::fprintf(stderr, "flatten_scene: %-12s %.3f s\n", what, std::chrono::duration<double>(t - t_prev).count()); t_prev = t; } };
     if (!world) { out.error = "world list is NULL"; return false; }
     Flattener f(out, time0, time1);
     for (int i = 0; i < world->index; i++)
@@ -684,25 +780,38 @@ bool flatten_scene(const hittable_list *world, const hittable_list *lights, cons
             } else l.kind = RTC_LIGHT_NONE;
             out.lights.push_back(l);
         }
+    lap("walk");
     build_small_pack(out);
     if ((int)out.prims.size() > bvh_threshold) {
         std::vector<BuildItem> items; std::vector<Box> item_boxes;
         box_items(out, f.prim_boxes, items, item_boxes);
         out.box_slots.clear();
-        Builder b{item_boxes, {}, out.nodes, out.leaf_prims, items, out.box_slots};
-        b.idx.resize(items.size());
-        for (size_t i = 0; i < b.idx.size(); i++) b.idx[i] = (int)i;
-        out.nodes.reserve(out.prims.size());
-        Builder::Child root = b.build(0, (int)b.idx.size());
+        std::vector<int> idx(items.size());
+        for (size_t i = 0; i < idx.size(); i++) idx[i] = (int)i;
+        lap("items");
+        // RTC_BUILD_THREADS: 1 = the sequential builder; default = the machine's cores, at most 16, for scenes of >= 50k items
+        int threads = (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+        if (const char *e = std::getenv("RTC_BUILD_THREADS")) threads = std::max(1, std::atoi(e));
+        Builder::Child root; int max_depth = 0;
+        if (threads > 1 && (items.size() >= 50000 || std::getenv("RTC_BUILD_THREADS")))
+            root = build_bvh_parallel(item_boxes, items, idx, threads, out.nodes, out.leaf_prims, out.box_slots, max_depth);
+        else {
+            Builder b{item_boxes, idx, out.nodes, out.leaf_prims, items, out.box_slots};
+            out.nodes.reserve(out.prims.size());
+            root = b.build(0, (int)idx.size()); max_depth = b.max_depth;
+        }
+        lap("bvh build");
         if (root.count > 0) {   // degenerate: everything fell into one leaf -> wrap it in a node
             BvhNode nd; std::memset(&nd, 0, sizeof nd);
             for (int a = 0; a < 3; a++) { nd.lo0[a] = Builder::down(root.box.lo[a]); nd.hi0[a] = Builder::up(root.box.hi[a]); nd.lo1[a] = 1; nd.hi1[a] = -1; }
             nd.child0 = rtc_leaf_ref(root.child, root.count); nd.count0 = root.count; nd.child1 = RTC_BVH_EMPTY; nd.count1 = 0;
             out.nodes.clear(); out.nodes.push_back(nd);
         }
-        out.bvh_depth = b.max_depth;
+        out.bvh_depth = max_depth;
         build_bleaves(out);
+        lap("leaves");
         build_leaf_shade(out);
+        lap("leaf shade");
     }
     return true;
 }

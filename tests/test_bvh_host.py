@@ -156,3 +156,18 @@ def test_small_scenes_have_no_bvh(rtc):
         assert len(nodes) == 0 and len(leaves) == 0
     finally:
         sc.close()
+
+
+def test_parallel_builder_makes_the_sequential_tree(rtc, tmp_path, monkeypatch):
+    """flatten.cpp build_bvh_parallel: the top of the tree by one builder, the deferred ranges by several threads, spliced in
+    pre-order -- the same partitions, node numbering and leaf slot order as the one-thread builder: the scene files are equal
+    byte for byte (the tree, the traversal leaves, the shading records, everything)."""
+    for name, arg in (("million", 200), ("final", 0), ("box_field_smoke", 0), ("book1", 0)):
+        blobs = []
+        for threads in ("1", "5"):
+            monkeypatch.setenv("RTC_BUILD_THREADS", threads)             # read by flatten_scene at every build; forces the parallel path
+            sc, _, _ = rtc.build_named_scene(name, arg=arg, host_only=True)
+            path = str(tmp_path / f"{name}_{threads}.rtcscene")
+            sc.save(path); sc.close()
+            blobs.append(open(path, "rb").read())
+        assert blobs[0] == blobs[1], name

@@ -39,6 +39,7 @@ struct Flattener {
     }
 
     int chain_id() {
+        if (cur.empty()) return 0;                        // no wrapper: the empty chain (nearly every leaf of a large scene)
         std::vector<double> key;
         for (const auto &o : cur) { key.push_back(o.type); key.push_back(o.axis); key.push_back(o.a); key.push_back(o.b); key.push_back(o.c); }
         auto it = chain_ids.find(key);

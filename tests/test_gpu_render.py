@@ -232,6 +232,28 @@ def test_small_scene_kernel_agrees_with_general_kernel(gpu, name, integrator, bl
     assert abs(sa["rays"] / sa["samples"] - sb["rays"] / sb["samples"]) <= 0.005 * sa["rays"] / sa["samples"]
 
 
+def test_small_scene_kernel_thin_lens_camera(gpu):
+    """The LENS = true build of the small-scene kernel (a camera with an aperture: origin and direction both come from the
+    primary-ray buffers) against the general kernel, as above: Cornell through a wide lens focused on the front of the room."""
+    sc, cam0, view = gpu.build_named_scene("cornell")
+    cam = gpu.Camera((view.lookfrom.x, view.lookfrom.y, view.lookfrom.z), (view.lookat.x, view.lookat.y, view.lookat.z),
+                     (view.vup.x, view.vup.y, view.vup.z), view.vfov, 1.0, 150.0, 800.0, view.time0, view.time1)
+    try:
+        a, sa = sc.render(cam, gpu.Settings(96, 96, 4096, view.max_depth, view.integrator, seed=1, kernel=1))
+        b, sb = sc.render(cam, gpu.Settings(96, 96, 4096, view.max_depth, view.integrator, seed=2, kernel=2))
+        sharp, _ = sc.render(cam0, gpu.Settings(96, 96, 1024, view.max_depth, view.integrator, seed=3, kernel=2))
+    finally:
+        sc.close()
+    assert sa["kernel_used"] == 1 and sb["kernel_used"] == 2
+    ia, ib, i0 = clip01(mean_image(a)), clip01(mean_image(b)), clip01(mean_image(sharp))
+    blk = np.sqrt(((block_means(ia) - block_means(ib)) ** 2).mean(axis=(0, 1)))
+    la, lb = (ia @ LUMA).mean(), (ib @ LUMA).mean()
+    print(f"lens: blk4 {blk.round(5)} dlum {abs(la - lb) / lb:.5f} rays/sample {sa['rays'] / sa['samples']:.4f} vs {sb['rays'] / sb['samples']:.4f}")
+    assert blk.max() <= 0.004 and abs(la - lb) / lb <= 0.005
+    assert abs(sa["rays"] / sa["samples"] - sb["rays"] / sb["samples"]) <= 0.005 * sa["rays"] / sa["samples"]
+    assert np.sqrt(((block_means(ib) - block_means(i0)) ** 2).mean()) > 0.01      # and the lens does blur: not the pinhole image
+
+
 def test_small_scene_kernel_refuses_ineligible_scenes(gpu):
     sc, cam, view = gpu.build_named_scene("cornell_smoke")      # constant media: not a small scene
     try:

@@ -254,6 +254,33 @@ def test_small_scene_kernel_thin_lens_camera(gpu):
     assert np.sqrt(((block_means(ib) - block_means(i0)) ** 2).mean()) > 0.01      # and the lens does blur: not the pinhole image
 
 
+def test_small_scene_kernel_fuzzy_metal_and_sky(gpu):
+    """Paths of the small-scene kernel that no built-in small scene takes: a metal with fuzz (the reflected direction is
+    perturbed and renormalised), the 01 sky integrator (01 main.c:39-65), spheres only, a thin-lens camera -- the three big
+    spheres of Book 1 on their ground sphere (01 main.c:108-114), built through the constructor API, against the general kernel."""
+    L = gpu.lib()
+    v3 = gpu.api.v3
+    world = L.hittable_list_new(8)
+    L.hittable_sphere_new(world, v3((0, -1000, 0)), 1000.0, L.material_lambertian_new_from_color(v3((0.5, 0.5, 0.5))))
+    L.hittable_sphere_new(world, v3((0, 1, 0)), 1.0, L.material_dielectric_new(1.5))
+    L.hittable_sphere_new(world, v3((-4, 1, 0)), 1.0, L.material_lambertian_new_from_color(v3((0.4, 0.2, 0.1))))
+    L.hittable_sphere_new(world, v3((4, 1, 0)), 1.0, L.material_metal_new(v3((0.7, 0.6, 0.5)), 0.3))
+    sc = gpu.Scene(world, None, (0, 0, 0))
+    cam = gpu.Camera((13, 2, 3), (0, 0, 0), (0, 1, 0), 20.0, 1.5, 0.1, 10.0)
+    try:
+        a, sa = sc.render(cam, gpu.Settings(96, 64, 4096, 8, 2, seed=1, kernel=1))
+        b, sb = sc.render(cam, gpu.Settings(96, 64, 4096, 8, 2, seed=2, kernel=2))
+    finally:
+        sc.close()
+    assert sa["kernel_used"] == 1 and sb["kernel_used"] == 2
+    ia, ib = clip01(mean_image(a)), clip01(mean_image(b))
+    blk = np.sqrt(((block_means(ia) - block_means(ib)) ** 2).mean(axis=(0, 1)))
+    la, lb = (ia @ LUMA).mean(), (ib @ LUMA).mean()
+    print(f"fuzzy/sky: blk4 {blk.round(5)} dlum {abs(la - lb) / lb:.5f} rays/sample {sa['rays'] / sa['samples']:.4f} vs {sb['rays'] / sb['samples']:.4f}")
+    assert blk.max() <= 0.004 and abs(la - lb) / lb <= 0.005
+    assert abs(sa["rays"] / sa["samples"] - sb["rays"] / sb["samples"]) <= 0.005 * sa["rays"] / sa["samples"]
+
+
 def test_small_scene_kernel_refuses_ineligible_scenes(gpu):
     sc, cam, view = gpu.build_named_scene("cornell_smoke")      # constant media: not a small scene
     try:

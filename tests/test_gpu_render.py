@@ -281,6 +281,43 @@ def test_small_scene_kernel_fuzzy_metal_and_sky(gpu):
     assert abs(sa["rays"] / sa["samples"] - sb["rays"] / sb["samples"]) <= 0.005 * sa["rays"] / sa["samples"]
 
 
+def test_small_scene_kernel_lights_on_every_axis(gpu):
+    """The light-list pdf and sampling of the small-scene kernel (kernels_small.hip small_light_pdf_one, its own algebra) for
+    rect lights in the YZ and XY planes -- the reference's scenes only have XZ lights (03 main.c:41) -- against the general
+    kernel (rt_shade.hpp light_pdf_one): a closed room lit from a side wall and from the back wall, 03 integrator."""
+    L = gpu.lib()
+    v3 = gpu.api.v3
+    XY, XZ, YZ = 0, 1, 2
+    world = L.hittable_list_new(16)
+    lights = L.hittable_list_new_no_gc(4)
+    white = L.material_lambertian_new_from_color(v3((0.73, 0.73, 0.73)))
+    red = L.material_lambertian_new_from_color(v3((0.65, 0.05, 0.05)))
+    lamp = L.material_light_new_from_color(v3((9, 9, 9)))
+    R = lambda x0, x1, y0, y1, z0, z1, k, axis, m, w=world: L.hittable_rect_new(w, x0, x1, y0, y1, z0, z1, k, axis, m)
+    R(0, 0, 0, 555, 0, 555, 555, YZ, red); R(0, 0, 0, 555, 0, 555, 0, YZ, white)          # side walls
+    R(0, 555, 0, 0, 0, 555, 0, XZ, white); R(0, 555, 0, 0, 0, 555, 555, XZ, white)        # floor, ceiling
+    R(0, 555, 0, 555, 0, 0, 555, XY, white)                                                 # back wall
+    side = R(0, 0, 200, 350, 150, 400, 1, YZ, lamp, None)                                   # lamp just inside the x = 0 wall, facing +x
+    back = R(180, 380, 300, 420, 0, 0, 554, XY, lamp, None)                                 # lamp just in front of the back wall
+    L.hittable_list_add(world, side); L.hittable_list_add(lights, side)
+    fb = L.hittable_flip_face_init(world, back); L.hittable_list_add(lights, back)          # faces -z, towards the camera
+    L.hittable_sphere_new(world, v3((300, 120, 250)), 120.0, white)
+    sc = gpu.Scene(world, lights, (0, 0, 0))
+    cam = gpu.Camera((278, 278, -800), (278, 278, 0), (0, 1, 0), 40.0, 1.0, 0.0, 10.0)
+    try:
+        a, sa = sc.render(cam, gpu.Settings(96, 96, 4096, 10, 0, seed=1, kernel=1))
+        b, sb = sc.render(cam, gpu.Settings(96, 96, 4096, 10, 0, seed=2, kernel=2))
+    finally:
+        sc.close()
+    assert sa["kernel_used"] == 1 and sb["kernel_used"] == 2
+    ia, ib = clip01(mean_image(a)), clip01(mean_image(b))
+    blk = np.sqrt(((block_means(ia) - block_means(ib)) ** 2).mean(axis=(0, 1)))
+    la, lb = (ia @ LUMA).mean(), (ib @ LUMA).mean()
+    print(f"axes: blk4 {blk.round(5)} dlum {abs(la - lb) / lb:.5f} rays/sample {sa['rays'] / sa['samples']:.4f} vs {sb['rays'] / sb['samples']:.4f} mean lum {lb:.4f}")
+    assert lb > 0.05 and blk.max() <= 0.006 and abs(la - lb) / lb <= 0.005      # a bright room: 1.5x the noise of the Cornell box at equal spp
+    assert abs(sa["rays"] / sa["samples"] - sb["rays"] / sb["samples"]) <= 0.005 * sa["rays"] / sa["samples"]
+
+
 def test_small_scene_kernel_refuses_ineligible_scenes(gpu):
     sc, cam, view = gpu.build_named_scene("cornell_smoke")      # constant media: not a small scene
     try:

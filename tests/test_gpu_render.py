@@ -307,10 +307,18 @@ def test_small_scene_kernel_lights_on_every_axis(gpu):
     try:
         a, sa = sc.render(cam, gpu.Settings(96, 96, 4096, 10, 0, seed=1, kernel=1))
         b, sb = sc.render(cam, gpu.Settings(96, 96, 4096, 10, 0, seed=2, kernel=2))
+        # the same image without importance sampling (cosine law only: neither the light pdf nor the light sampling is used) and
+        # with half of the samples sent to the lights: a wrong pdf or a wrong sampler would bias one against the other
+        c, _ = sc.render(cam, gpu.Settings(96, 96, 32768, 10, 0, seed=3, kernel=2, mixture_light_weight=0.0))
+        d, _ = sc.render(cam, gpu.Settings(96, 96, 8192, 10, 0, seed=4, kernel=2, mixture_light_weight=0.5))
     finally:
         sc.close()
     assert sa["kernel_used"] == 1 and sb["kernel_used"] == 2
     ia, ib = clip01(mean_image(a)), clip01(mean_image(b))
+    lc, ld = (mean_image(c) @ LUMA).mean(), (mean_image(d) @ LUMA).mean()
+    lin_b = (mean_image(b) @ LUMA).mean()
+    print(f"axes: mean radiance cosine-only {lc:.5f}, weight 0.1 {lin_b:.5f}, weight 0.5 {ld:.5f}")
+    assert abs(lc - ld) / ld <= 0.01 and abs(lin_b - ld) / ld <= 0.01
     blk = np.sqrt(((block_means(ia) - block_means(ib)) ** 2).mean(axis=(0, 1)))
     la, lb = (ia @ LUMA).mean(), (ib @ LUMA).mean()
     print(f"axes: blk4 {blk.round(5)} dlum {abs(la - lb) / lb:.5f} rays/sample {sa['rays'] / sa['samples']:.4f} vs {sb['rays'] / sb['samples']:.4f} mean lum {lb:.4f}")

@@ -326,6 +326,52 @@ def test_small_scene_kernel_lights_on_every_axis(gpu):
     assert abs(sa["rays"] / sa["samples"] - sb["rays"] / sb["samples"]) <= 0.005 * sa["rays"] / sa["samples"]
 
 
+def test_wavefront_with_the_03_integrator_and_lights(gpu):
+    """The reference's BVH scenes all run the 02 / 01 integrators; the wavefront pipeline's 03 branch (mixture pdf over a light
+    list, rt_shade.hpp shade_hit_mat) therefore gets its own scene: the two-lamp room above with 90 spheres (a BVH scene), rendered
+    by the wavefront kernels and by the megakernel with the same Philox keys (tight agreement), and with mixture weights 0 and 0.5
+    (same mean radiance: the light pdfs and samplers are consistent with the cosine law)."""
+    L = gpu.lib()
+    v3 = gpu.api.v3
+    XY, XZ, YZ = 0, 1, 2
+    world = L.hittable_list_new(128)
+    lights = L.hittable_list_new_no_gc(4)
+    white = L.material_lambertian_new_from_color(v3((0.73, 0.73, 0.73)))
+    red = L.material_lambertian_new_from_color(v3((0.65, 0.05, 0.05)))
+    lamp = L.material_light_new_from_color(v3((9, 9, 9)))
+    steel = L.material_metal_new(v3((0.8, 0.85, 0.88)), 0.05)
+    glass = L.material_dielectric_new(1.5)
+    R = lambda x0, x1, y0, y1, z0, z1, k, axis, m, w=world: L.hittable_rect_new(w, x0, x1, y0, y1, z0, z1, k, axis, m)
+    R(0, 0, 0, 555, 0, 555, 555, YZ, red); R(0, 0, 0, 555, 0, 555, 0, YZ, white)
+    R(0, 555, 0, 0, 0, 555, 0, XZ, white); R(0, 555, 0, 0, 0, 555, 555, XZ, white)
+    R(0, 555, 0, 555, 0, 0, 555, XY, white)
+    side = R(0, 0, 200, 350, 150, 400, 1, YZ, lamp, None)
+    back = R(180, 380, 300, 420, 0, 0, 554, XY, lamp, None)
+    L.hittable_list_add(world, side); L.hittable_list_add(lights, side)
+    L.hittable_flip_face_init(world, back); L.hittable_list_add(lights, back)
+    ball = L.hittable_sphere_new(world, v3((420, 90, 200)), 90.0, glass); L.hittable_list_add(lights, ball)   # a sphere in the light list, as in 03 main.c:76
+    for i in range(90):
+        m = (white, steel, glass)[i % 3]
+        L.hittable_sphere_new(world, v3((40 + 52 * (i % 10), 20 + 7 * (i % 4), 60 + 50 * (i // 10))), 18.0 + (i % 5), m)
+    sc = gpu.Scene(world, lights, (0, 0, 0))
+    cam = gpu.Camera((278, 278, -800), (278, 278, 0), (0, 1, 0), 40.0, 1.0, 0.0, 10.0)
+    try:
+        assert sc.bvh_info()["nodes"] > 0
+        a, sa = sc.render(cam, gpu.Settings(96, 96, 512, 10, 0, seed=5, kernel=1))
+        b, sb = sc.render(cam, gpu.Settings(96, 96, 512, 10, 0, seed=5, kernel=3))
+        c, _ = sc.render(cam, gpu.Settings(96, 96, 32768, 10, 0, seed=6, kernel=3, mixture_light_weight=0.0))
+        d, _ = sc.render(cam, gpu.Settings(96, 96, 8192, 10, 0, seed=7, kernel=3, mixture_light_weight=0.5))
+    finally:
+        sc.close()
+    assert sa["kernel_used"] == 1 and sb["kernel_used"] == 3
+    ia, ib = clip01(mean_image(a)), clip01(mean_image(b))
+    blk = np.sqrt(((block_means(ia) - block_means(ib)) ** 2).mean(axis=(0, 1)))
+    lb, lc, ld = (mean_image(b) @ LUMA).mean(), (mean_image(c) @ LUMA).mean(), (mean_image(d) @ LUMA).mean()
+    print(f"wavefront 03: blk4 {blk.round(5)} rays/sample {sa['rays'] / sa['samples']:.4f} vs {sb['rays'] / sb['samples']:.4f}; mean radiance weight 0 / 0.1 / 0.5: {lc:.5f} {lb:.5f} {ld:.5f}")
+    assert blk.max() <= 0.002 and abs(sa["rays"] - sb["rays"]) <= 0.005 * sa["rays"]
+    assert abs(lc - ld) / ld <= 0.01
+
+
 def test_full_size_mixture_weight_invariance(gpu):
     """A size-independent property at BASELINE config 2's full size (1920x1080, 256 spp, depth 10): the mixture weight of
     pdf.c:119-121 changes the variance of the estimator, never its mean -- Cornell rendered with weight 0.1 (ray.c:72), 0.5 and

@@ -394,7 +394,10 @@ int rtc_render_device(const rtc_scene *scene_c, const camera *cam, const rtc_set
     p.width = st->width; p.height = st->height; p.s_begin = st->sample_begin; p.s_end = st->sample_end;
     p.max_depth = st->max_depth; p.integrator = st->integrator;
     p.seed_lo = (uint32_t)st->seed; p.seed_hi = (uint32_t)(st->seed >> 32);
-    p.light_weight = (float)st->mixture_light_weight;
+    // An empty light list leaves nothing to mix: the cosine law alone (weight 0).  The reference has no defined answer here --
+    // pdf_generate would call hittable_list_random on an empty list (hittable_list.c:174-180: random_int(0, -1)) -- and keeping
+    // the weight would scale every bounce by 1 / (1 - w).
+    p.light_weight = s->flat.lights.empty() ? 0.0f : (float)st->mixture_light_weight;
     p.light_weight_each = s->flat.lights.empty() ? 0.0f : p.light_weight / (float)s->flat.lights.size(); p.cosine_weight = 1.0f - p.light_weight;
     p.tiles_x = (st->width + 7) / 8; p.tiles_y = (st->height + 7) / 8; p.n_tiles = p.tiles_x * p.tiles_y;
     const CameraT<float> camf = camera_tables<float>(cam);

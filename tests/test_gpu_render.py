@@ -372,6 +372,34 @@ def test_wavefront_with_the_03_integrator_and_lights(gpu):
     assert abs(lc - ld) / ld <= 0.01
 
 
+def test_03_integrator_without_a_light_list(gpu):
+    """An empty `lights` list under the 03 integrator (hittable_list_pdf_value over nothing, pdf.c:119-121 with a zero light term):
+    the mixture degenerates to (1 - w) x the cosine pdf in both kernels; the lamp is found by chance only.  Small-scene kernel
+    against the general kernel, and weight 0.1 against weight 0 (the estimator's mean does not depend on w)."""
+    L = gpu.lib()
+    v3 = gpu.api.v3
+    XY, XZ, YZ = 0, 1, 2
+    world = L.hittable_list_new(16)
+    white = L.material_lambertian_new_from_color(v3((0.73, 0.73, 0.73)))
+    lamp = L.material_light_new_from_color(v3((4, 4, 4)))
+    R = lambda x0, x1, y0, y1, z0, z1, k, axis, m: L.hittable_rect_new(world, x0, x1, y0, y1, z0, z1, k, axis, m)
+    R(0, 0, 0, 555, 0, 555, 555, YZ, white); R(0, 0, 0, 555, 0, 555, 0, YZ, white)
+    R(0, 555, 0, 0, 0, 555, 0, XZ, white); R(0, 555, 0, 555, 0, 0, 555, XY, white)
+    L.hittable_flip_face_init(world, L.hittable_rect_new(None, 0, 555, 0, 0, 0, 555, 554, XZ, lamp))   # the whole ceiling glows downwards
+    sc = gpu.Scene(world, None, (0, 0, 0))
+    cam = gpu.Camera((278, 278, -800), (278, 278, 0), (0, 1, 0), 40.0, 1.0, 0.0, 10.0)
+    try:
+        a, sa = sc.render(cam, gpu.Settings(64, 64, 2048, 10, 0, seed=1, kernel=1))
+        b, sb = sc.render(cam, gpu.Settings(64, 64, 2048, 10, 0, seed=2, kernel=2))
+        c, _ = sc.render(cam, gpu.Settings(64, 64, 2048, 10, 0, seed=3, kernel=2, mixture_light_weight=0.0))
+    finally:
+        sc.close()
+    assert sa["kernel_used"] == 1 and sb["kernel_used"] == 2 and np.isfinite(a).all() and np.isfinite(b).all()
+    la, lb, lc = [(mean_image(x) @ LUMA).mean() for x in (a, b, c)]
+    print(f"no light list: mean radiance general {la:.5f} small {lb:.5f} small, weight 0 {lc:.5f}")
+    assert lb > 0.1 and abs(la - lb) / lb <= 0.005 and abs(lc - lb) / lb <= 0.005
+
+
 def test_full_size_mixture_weight_invariance(gpu):
     """A size-independent property at BASELINE config 2's full size (1920x1080, 256 spp, depth 10): the mixture weight of
     pdf.c:119-121 changes the variance of the estimator, never its mean -- Cornell rendered with weight 0.1 (ray.c:72), 0.5 and

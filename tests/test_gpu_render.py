@@ -400,6 +400,52 @@ def test_03_integrator_without_a_light_list(gpu):
     assert lb > 0.1 and abs(la - lb) / lb <= 0.005 and abs(lc - lb) / lb <= 0.005
 
 
+def test_small_scene_limit_of_64_leaves(gpu):
+    """RTC_SMALL_MAX_LEAVES: ten rotated boxes (60 rects, ten object spaces) and four more rects are exactly 64 leaves and still
+    take the small-scene kernel (the leaf ids fill the 48-B x 64 LDS table and the id bytes of the box records up to 63); one
+    more sphere makes it a BVH scene for the wavefront kernels.  Both against the general kernel."""
+    L = gpu.lib()
+    v3 = gpu.api.v3
+    XY, XZ, YZ = 0, 1, 2
+
+    def build(extra):
+        world = L.hittable_list_new(32)
+        lights = L.hittable_list_new_no_gc(2)
+        white = L.material_lambertian_new_from_color(v3((0.73, 0.73, 0.73)))
+        green = L.material_lambertian_new_from_color(v3((0.12, 0.45, 0.15)))
+        steel = L.material_metal_new(v3((0.8, 0.85, 0.88)), 0.0)
+        lamp = L.material_light_new_from_color(v3((15, 15, 15)))
+        L.hittable_rect_new(world, 0, 555, 0, 0, 0, 555, 0, XZ, white)
+        L.hittable_rect_new(world, 0, 555, 0, 555, 0, 0, 555, XY, white)
+        L.hittable_rect_new(world, 0, 0, 0, 555, 0, 555, 555, YZ, green)
+        light = L.hittable_rect_new(None, 163, 393, 0, 0, 177, 382, 554, XZ, lamp)
+        L.hittable_flip_face_init(world, light); L.hittable_list_add(lights, light)
+        for i in range(10):
+            b = L.hittable_box_new(None, v3((0, 0, 0)), v3((70, 60 + 25 * (i % 4), 70)), steel if i % 4 == 0 else white)
+            b = L.hittable_rotate_init(None, b, -30.0 + 9.0 * i, 1)                                   # about y
+            L.hittable_translate_init(world, b, v3((30 + 100 * (i % 5), 0, 80 + 220 * (i // 5))))
+        if extra:
+            L.hittable_sphere_new(world, v3((278, 300, 278)), 60.0, L.material_dielectric_new(1.5))
+        return gpu.Scene(world, lights, (0, 0, 0))
+
+    cam = gpu.Camera((278, 278, -800), (278, 278, 0), (0, 1, 0), 40.0, 1.0, 0.0, 10.0)
+    for extra, kernel in ((False, 2), (True, 3)):
+        sc = build(extra)
+        try:
+            assert sc.num_prims() == 64 + extra and (sc.bvh_info()["nodes"] > 0) == extra
+            a, sa = sc.render(cam, gpu.Settings(96, 96, 8192, 10, 0, seed=1, kernel=1))
+            b, sb = sc.render(cam, gpu.Settings(96, 96, 8192, 10, 0, seed=2, kernel=0))
+        finally:
+            sc.close()
+        assert sa["kernel_used"] == 1 and sb["kernel_used"] == kernel
+        ia, ib = clip01(mean_image(a)), clip01(mean_image(b))
+        blk = np.sqrt(((block_means(ia) - block_means(ib)) ** 2).mean(axis=(0, 1)))
+        la, lb = (ia @ LUMA).mean(), (ib @ LUMA).mean()
+        print(f"{64 + extra} leaves, kernel {kernel}: blk4 {blk.round(5)} dlum {abs(la - lb) / lb:.5f} rays/sample {sa['rays'] / sa['samples']:.4f} vs {sb['rays'] / sb['samples']:.4f}")
+        assert blk.max() <= 0.006 and abs(la - lb) / lb <= 0.005
+        assert abs(sa["rays"] / sa["samples"] - sb["rays"] / sb["samples"]) <= 0.005 * sa["rays"] / sa["samples"]
+
+
 def test_full_size_mixture_weight_invariance(gpu):
     """A size-independent property at BASELINE config 2's full size (1920x1080, 256 spp, depth 10): the mixture weight of
     pdf.c:119-121 changes the variance of the estimator, never its mean -- Cornell rendered with weight 0.1 (ray.c:72), 0.5 and

@@ -256,13 +256,14 @@ def test_small_scene_kernel_thin_lens_camera(gpu):
 
 def test_small_scene_kernel_fuzzy_metal_and_sky(gpu):
     """Paths of the small-scene kernel that no built-in small scene takes: a metal with fuzz (the reflected direction is
-    perturbed and renormalised), the 01 sky integrator (01 main.c:39-65), spheres only, a thin-lens camera -- the three big
+    perturbed and renormalised), the 01 sky integrator (01 main.c:39-65), spheres only, a negative radius, a thin-lens camera -- the three big
     spheres of Book 1 on their ground sphere (01 main.c:108-114), built through the constructor API, against the general kernel."""
     L = gpu.lib()
     v3 = gpu.api.v3
     world = L.hittable_list_new(8)
     L.hittable_sphere_new(world, v3((0, -1000, 0)), 1000.0, L.material_lambertian_new_from_color(v3((0.5, 0.5, 0.5))))
     L.hittable_sphere_new(world, v3((0, 1, 0)), 1.0, L.material_dielectric_new(1.5))
+    L.hittable_sphere_new(world, v3((0, 1, 0)), -0.9, L.material_dielectric_new(1.5))     # negative radius: a hollow glass ball (its normal points inwards)
     L.hittable_sphere_new(world, v3((-4, 1, 0)), 1.0, L.material_lambertian_new_from_color(v3((0.4, 0.2, 0.1))))
     L.hittable_sphere_new(world, v3((4, 1, 0)), 1.0, L.material_metal_new(v3((0.7, 0.6, 0.5)), 0.3))
     sc = gpu.Scene(world, None, (0, 0, 0))

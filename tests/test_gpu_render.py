@@ -488,6 +488,42 @@ def test_light_list_entry_that_is_not_a_light_shape(gpu):
         assert abs(sa["rays"] / sa["samples"] - sb["rays"] / sb["samples"]) <= 0.005 * sa["rays"] / sa["samples"]
 
 
+def test_moving_spheres_without_and_with_a_bvh(gpu):
+    """moving_sphere_hit (hittable.c:462-481) in the general kernel's brute-force loop -- the reference's scenes only put moving
+    spheres into BVH scenes -- against the wavefront kernels: the same eight moving spheres over a ground sphere, once alone
+    (9 leaves: general kernel, no BVH) and once with 80 tiny spheres parked far behind the camera (a BVH scene that looks the same),
+    same Philox keys, open shutter."""
+    L = gpu.lib()
+    v3 = gpu.api.v3
+
+    def build(pad):
+        world = L.hittable_list_new(128)
+        L.hittable_sphere_new(world, v3((0, -1000, 0)), 1000.0, L.material_lambertian_new_from_color(v3((0.5, 0.5, 0.5))))
+        for i in range(8):
+            m = L.material_lambertian_new_from_color(v3((0.2 + 0.1 * i, 0.3, 0.9 - 0.1 * i))) if i % 2 else L.material_metal_new(v3((0.8, 0.8, 0.7)), 0.1 * (i % 3))
+            c0 = (-7 + 2 * i, 0.6, -1 + 0.7 * (i % 3))
+            L.hittable_moving_sphere_new(world, v3(c0), v3((c0[0] + 0.3, c0[1] + 0.5 * (i % 2), c0[2])), 0.0, 1.0, 0.6, m)
+        for i in range(pad):
+            L.hittable_sphere_new(world, v3((1e6 + 10 * i, 1e6, 1e6)), 0.5, L.material_dielectric_new(1.5))
+        return gpu.Scene(world, None, (0, 0, 0), 0.0, 1.0)
+
+    cam = gpu.Camera((13, 2, 3), (0, 0, 0), (0, 1, 0), 35.0, 1.5, 0.0, 10.0, 0.0, 1.0)
+    plain, padded = build(0), build(80)
+    try:
+        assert plain.bvh_info()["nodes"] == 0 and padded.bvh_info()["nodes"] > 0
+        a, sa = plain.render(cam, gpu.Settings(96, 64, 1024, 8, 2, seed=4))
+        b, sb = padded.render(cam, gpu.Settings(96, 64, 1024, 8, 2, seed=4))
+        still, _ = plain.render(gpu.Camera((13, 2, 3), (0, 0, 0), (0, 1, 0), 35.0, 1.5, 0.0, 10.0, 0.0, 0.0), gpu.Settings(96, 64, 1024, 8, 2, seed=4))
+    finally:
+        plain.close(); padded.close()
+    assert sa["kernel_used"] == 1 and sb["kernel_used"] == 3
+    ia, ib, i0 = clip01(mean_image(a)), clip01(mean_image(b)), clip01(mean_image(still))
+    blk = np.sqrt(((block_means(ia) - block_means(ib)) ** 2).mean(axis=(0, 1)))
+    print(f"moving spheres: blk4 {blk.round(5)} rays {sa['rays']} vs {sb['rays']}; against the closed shutter {np.sqrt(((block_means(ia) - block_means(i0)) ** 2).mean()):.4f}")
+    assert blk.max() <= 0.001 and abs(sa["rays"] - sb["rays"]) <= 0.005 * sa["rays"]
+    assert np.sqrt(((block_means(ia) - block_means(i0)) ** 2).mean()) > 0.005       # the shutter does blur them
+
+
 def test_full_size_mixture_weight_invariance(gpu):
     """A size-independent property at BASELINE config 2's full size (1920x1080, 256 spp, depth 10): the mixture weight of
     pdf.c:119-121 changes the variance of the estimator, never its mean -- Cornell rendered with weight 0.1 (ray.c:72), 0.5 and

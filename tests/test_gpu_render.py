@@ -211,6 +211,30 @@ def test_render_device_on_a_torch_stream(gpu):
         sc.close()
 
 
+def test_renders_of_one_scene_on_two_streams_overlap_safely(gpu):
+    """small-scene renders of one scene enqueued on different streams may overlap on the GPU -- each stream
+    has its own tile order, partial planes and events.  Two renders large enough to overlap (different sizes, seeds and sample
+    ranges), enqueued back to back on two streams, equal the same renders done one at a time, bit for bit."""
+    import torch
+    from raytracer_amd import dist as rd
+    sc, cam, view = gpu.build_named_scene("cornell")
+    try:
+        jobs = [gpu.Settings(640, 480, 0, 10, 0, seed=31, sample_begin=0, sample_end=96), gpu.Settings(512, 512, 0, 10, 0, seed=32, sample_begin=7, sample_end=71)]
+        alone = [sc.render(cam, st)[0] for st in jobs]
+        for rep in range(2):                                         # second pass: the cached tile orders of both streams are reused
+            accs = [rd.new_accum(st.c.height, st.c.width, "cuda:0") for st in jobs]
+            streams = [torch.cuda.Stream(), torch.cuda.Stream()] if rep == 0 else streams
+            torch.cuda.synchronize()
+            for st, acc, side in zip(jobs, accs, streams):
+                with torch.cuda.stream(side):
+                    rd.render_into(sc, cam, st, acc)
+            torch.cuda.synchronize()
+            for acc, want in zip(accs, alone):
+                assert np.array_equal(acc.cpu().numpy(), want)
+    finally:
+        sc.close()
+
+
 @pytest.mark.parametrize("name,integrator,blk_tol", [("cornell", 0, 0.004), ("simple", 0, 0.004), ("cornell02", 1, 0.008)])
 def test_small_scene_kernel_agrees_with_general_kernel(gpu, name, integrator, blk_tol):
     """kernel=2 (packed leaves, LDS shading records, basis-free cosine sampling) and kernel=1 (general megakernel) are

@@ -116,11 +116,12 @@ struct rtc_scene {
     DeviceTables<double> f64;
     DevBuf ray_counter;
     DevBuf wf_pool; size_t wf_slots_cap = 0;   // wavefront path-slot state, grown on demand
+    hipEvent_t wf_done = nullptr;              // end of the last wavefront render's final accumulate: the pool is shared by all streams
     DevBuf small_pairs, small_groups, small_spheres, small_shade, small_xforms, small_boxes;
     SmallScene small{};   // n_leaves == 0: not eligible
     std::map<void *, StreamState> streams;
     std::mutex mu;
-    ~rtc_scene() { for (auto &kv : streams) { if (kv.second.ev0) (void)hipEventDestroy(kv.second.ev0); if (kv.second.ev1) (void)hipEventDestroy(kv.second.ev1); } }
+    ~rtc_scene() { if (wf_done) (void)hipEventDestroy(wf_done); for (auto &kv : streams) { if (kv.second.ev0) (void)hipEventDestroy(kv.second.ev0); if (kv.second.ev1) (void)hipEventDestroy(kv.second.ev1); } }
 };
 
 extern "C" {
@@ -340,8 +341,12 @@ static int render_wavefront(rtc_scene *s, const CameraT<float> &camf, const Rend
     const long long n_slots = per_layer * layers;
     if (n_slots > (1ll << 30)) return fail(RTC_ERR_ARG, "image too large for the wavefront path");
     const size_t per_slot = wf_bytes_per_slot();
+    // The previous render's final accumulate may still be in flight on ANOTHER stream and reads the pool this render is about
+    // to overwrite (this call returns with that kernel enqueued, not finished): order this stream behind it.
+    if (!s->wf_done) HIP_TRY(hipEventCreateWithFlags(&s->wf_done, hipEventDisableTiming));
+    else HIP_TRY(hipStreamWaitEvent(stream, s->wf_done, 0));
     if ((size_t)n_slots > s->wf_slots_cap) {
-        if (s->wf_pool.p) { HIP_TRY(hipStreamSynchronize(stream)); (void)hipFree(s->wf_pool.p); s->wf_pool.p = nullptr; s->wf_slots_cap = 0; }
+        if (s->wf_pool.p) { HIP_TRY(hipEventSynchronize(s->wf_done)); HIP_TRY(hipStreamSynchronize(stream)); (void)hipFree(s->wf_pool.p); s->wf_pool.p = nullptr; s->wf_slots_cap = 0; }
         if (hipMalloc(&s->wf_pool.p, (size_t)n_slots * per_slot + 256) != hipSuccess) { s->wf_pool.p = nullptr; return fail(RTC_ERR_NOMEM, "wavefront path-slot state does not fit in device memory"); }
         s->wf_slots_cap = (size_t)n_slots;
     }
@@ -378,6 +383,7 @@ static int render_wavefront(rtc_scene *s, const CameraT<float> &camf, const Rend
         for (int k = 0; k < 8 && it < max_iterations; ++k, ++it) HIP_TRY(launch_wf_bounce(s->f32.view, camf, p, b, cur, n_list, stream));
     }
     HIP_TRY(launch_wf_finish(p, b, accum, stream));
+    HIP_TRY(hipEventRecord(s->wf_done, stream));
     return RTC_OK;
 }
 

@@ -235,6 +235,30 @@ def test_renders_of_one_scene_on_two_streams_overlap_safely(gpu):
         sc.close()
 
 
+def test_wavefront_renders_on_two_streams_share_the_pool_in_order(gpu):
+    """The path-slot pool of a BVH scene is one per scene, and a wavefront render returns with its final accumulate still in
+    flight; a render enqueued on ANOTHER stream right behind it must not start overwriting the pool before that kernel has
+    read it (rtc_api.cpp: the scene's wf_done event).  Two renders on two streams, back to back, equal the renders done alone."""
+    import torch
+    from raytracer_amd import dist as rd
+    sc, cam, view = gpu.build_named_scene("book1")
+    try:
+        jobs = [gpu.Settings(320, 200, 16, view.max_depth, view.integrator, seed=41), gpu.Settings(256, 256, 24, view.max_depth, view.integrator, seed=42)]
+        alone = [sc.render(cam, st)[0] for st in jobs]
+        streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+        for rep in range(3):
+            accs = [rd.new_accum(st.c.height, st.c.width, "cuda:0") for st in jobs]
+            torch.cuda.synchronize()
+            for st, acc, side in zip(jobs, accs, streams):
+                with torch.cuda.stream(side):
+                    rd.render_into(sc, cam, st, acc)
+            torch.cuda.synchronize()
+            for acc, want in zip(accs, alone):
+                assert np.array_equal(acc.cpu().numpy(), want)
+    finally:
+        sc.close()
+
+
 @pytest.mark.parametrize("name,integrator,blk_tol", [("cornell", 0, 0.004), ("simple", 0, 0.004), ("cornell02", 1, 0.008)])
 def test_small_scene_kernel_agrees_with_general_kernel(gpu, name, integrator, blk_tol):
     """kernel=2 (packed leaves, LDS shading records, basis-free cosine sampling) and kernel=1 (general megakernel) are

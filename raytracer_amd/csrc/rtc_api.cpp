@@ -240,8 +240,17 @@ int rtc_scene_dump_bvh(const rtc_scene *scene, void *nodes16, int node_cap, void
     return (int)fs.bleaves.size();
 }
 
+// Every compute entry point: the scene has device tables, and they live on the calling thread's current device (a kernel
+// launched on another GPU with these pointers would fault it).
+static int check_device(const rtc_scene *s) {
+    if (s->device < 0) return fail(RTC_ERR_DEVICE, "scene was flattened on the host only (rtc_scene_flatten_only / rtc_scene_load_host): no device tables");
+    int cur = -1;
+    if (hipGetDevice(&cur) != hipSuccess) return fail(RTC_ERR_DEVICE, "no current HIP device");
+    if (cur != s->device) return fail(RTC_ERR_DEVICE, "scene lives on HIP device " + std::to_string(s->device) + ", the current device is " + std::to_string(cur));
+    return RTC_OK;
+}
 static int ensure_f64(rtc_scene *s) {
-    if (s->device < 0) return fail(RTC_ERR_DEVICE, "scene was flattened on the host only (rtc_scene_flatten_only): no device tables");
+    if (int rc_dev = check_device(s)) return rc_dev;
     if (s->f64.ready) return RTC_OK;
     HIP_TRY(upload_tables<double>(s->flat, s->f64, true));
     return RTC_OK;
@@ -291,7 +300,7 @@ int rtc_primary_first_hit_f64(const rtc_scene *scene_c, const camera *cam, const
 int rtc_first_hit_f32(const rtc_scene *scene_c, const double *rays7, size_t n, double tmin, double tmax, int32_t *prim_id, float *t) {
     rtc_scene *s = const_cast<rtc_scene *>(scene_c);
     if (!s || (!rays7 && n) || !prim_id || !t) return fail(RTC_ERR_ARG, "rtc_first_hit_f32: null argument");
-    if (s->device < 0) return fail(RTC_ERR_DEVICE, "scene was flattened on the host only (rtc_scene_flatten_only): no device tables");
+    if (int rc_dev = check_device(s)) return rc_dev;
     if (n == 0) return RTC_OK;
     std::lock_guard<std::mutex> lk(s->mu);
     std::vector<float> rf(n * 7);
@@ -390,7 +399,7 @@ static int render_wavefront(rtc_scene *s, const CameraT<float> &camf, const Rend
 int rtc_render_device(const rtc_scene *scene_c, const camera *cam, const rtc_settings *st, float *accum_dev, void *stream_v) {
     rtc_scene *s = const_cast<rtc_scene *>(scene_c);
     if (!s || !cam || !accum_dev) return fail(RTC_ERR_ARG, "rtc_render_device: null argument");
-    if (s->device < 0) return fail(RTC_ERR_DEVICE, "scene was flattened on the host only (rtc_scene_flatten_only): no device tables");
+    if (int rc_dev = check_device(s)) return rc_dev;
     int rc = check_settings(st); if (rc) return rc;
     hipStream_t stream = (hipStream_t)stream_v;
     std::lock_guard<std::mutex> lk(s->mu);

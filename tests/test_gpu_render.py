@@ -207,6 +207,13 @@ def test_render_device_on_a_torch_stream(gpu):
         assert np.array_equal(u8.cpu().numpy(), gpu.tonemap_u8(host))
         with pytest.raises(ValueError):
             rd.render_into(sc, cam, st, torch.zeros(40, 72, 4))
+        host_acc = np.zeros((40, 72, 4), dtype=np.float32)            # a host pointer must be refused before a kernel meets it
+        with pytest.raises(gpu.RtcError, match="host"):
+            sc.render_device(cam, st, host_acc.ctypes.data)
+        assert gpu.lib().rtc_tonemap_u8_device(host_acc.ctypes.data, 72, 40, u8.data_ptr(), None) != 0
+        pinned = torch.zeros((40, 72, 4), dtype=torch.float32).pin_memory()
+        with pytest.raises(gpu.RtcError, match="host"):
+            sc.render_device(cam, st, pinned.data_ptr())
     finally:
         sc.close()
 

@@ -250,12 +250,16 @@ static int check_device(const rtc_scene *s) {
     return RTC_OK;
 }
 // A pointer the caller says is device memory: refuse host memory and memory of another GPU before a kernel meets it.
-static int check_device_pointer(const void *ptr, const char *what) {
+static int check_device_pointer(const void *ptr, size_t bytes, const char *what) {
     hipPointerAttribute_t attr;
     if (hipPointerGetAttributes(&attr, ptr) != hipSuccess) { (void)hipGetLastError(); return fail(RTC_ERR_ARG, std::string(what) + " is not memory the HIP runtime knows (a host pointer?)"); }
     int cur = -1; (void)hipGetDevice(&cur);
     if (attr.type == hipMemoryTypeHost || attr.type == hipMemoryTypeUnregistered) return fail(RTC_ERR_ARG, std::string(what) + " is host memory; this entry point takes device memory");
     if (attr.type == hipMemoryTypeDevice && attr.device != cur) return fail(RTC_ERR_ARG, std::string(what) + " lives on HIP device " + std::to_string(attr.device) + ", the current device is " + std::to_string(cur));
+    hipDeviceptr_t base = nullptr; size_t size = 0;   // the allocation must reach as far as the kernel will write (a sub-allocator's block may hide a short tensor)
+    if (hipMemGetAddressRange(&base, &size, (hipDeviceptr_t)ptr) == hipSuccess) {
+        if ((const char *)ptr + bytes > (const char *)base + size) return fail(RTC_ERR_ARG, std::string(what) + " is shorter than the image needs (" + std::to_string(bytes) + " bytes)");
+    } else (void)hipGetLastError();
     return RTC_OK;
 }
 static int ensure_f64(rtc_scene *s) {
@@ -410,7 +414,7 @@ int rtc_render_device(const rtc_scene *scene_c, const camera *cam, const rtc_set
     if (!s || !cam || !accum_dev) return fail(RTC_ERR_ARG, "rtc_render_device: null argument");
     if (int rc_dev = check_device(s)) return rc_dev;
     int rc = check_settings(st); if (rc) return rc;
-    if (int rc_ptr = check_device_pointer(accum_dev, "rtc_render_device: accum_dev")) return rc_ptr;
+    if (int rc_ptr = check_device_pointer(accum_dev, (size_t)st->width * (size_t)st->height * 16, "rtc_render_device: accum_dev")) return rc_ptr;
     hipStream_t stream = (hipStream_t)stream_v;
     std::lock_guard<std::mutex> lk(s->mu);
     StreamState &ss = s->streams[stream_v];
@@ -515,8 +519,8 @@ int rtc_render(const rtc_scene *scene, const camera *cam, const rtc_settings *st
 
 int rtc_tonemap_u8_device(const float *accum_dev, int width, int height, unsigned char *rgb_dev, void *stream) {
     if (!accum_dev || !rgb_dev || width <= 0 || height <= 0) return fail(RTC_ERR_ARG, "rtc_tonemap_u8_device: bad argument");
-    if (int rc = check_device_pointer(accum_dev, "rtc_tonemap_u8_device: accum_dev")) return rc;
-    if (int rc = check_device_pointer(rgb_dev, "rtc_tonemap_u8_device: rgb_dev")) return rc;
+    if (int rc = check_device_pointer(accum_dev, (size_t)width * (size_t)height * 16, "rtc_tonemap_u8_device: accum_dev")) return rc;
+    if (int rc = check_device_pointer(rgb_dev, (size_t)width * (size_t)height * 3, "rtc_tonemap_u8_device: rgb_dev")) return rc;
     HIP_TRY(launch_tonemap_u8((const float4 *)accum_dev, width * height, rgb_dev, (hipStream_t)stream));
     return RTC_OK;
 }

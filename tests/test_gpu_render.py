@@ -211,6 +211,9 @@ def test_render_device_on_a_torch_stream(gpu):
         with pytest.raises(gpu.RtcError, match="host"):
             sc.render_device(cam, st, host_acc.ctypes.data)
         assert gpu.lib().rtc_tonemap_u8_device(host_acc.ctypes.data, 72, 40, u8.data_ptr(), None) != 0
+        big = gpu.Settings(4096, 4096, 1, 10, 0, seed=1)              # 268 MB of accumulator: no 46-KB tensor's allocation reaches that far
+        with pytest.raises(gpu.RtcError, match="shorter"):
+            sc.render_device(cam, big, acc.data_ptr())
         pinned = torch.zeros((40, 72, 4), dtype=torch.float32).pin_memory()
         with pytest.raises(gpu.RtcError, match="host"):
             sc.render_device(cam, st, pinned.data_ptr())

@@ -582,6 +582,37 @@ def test_moving_spheres_without_and_with_a_bvh(gpu):
     assert np.sqrt(((block_means(ia) - block_means(i0)) ** 2).mean()) > 0.005       # the shutter does blur them
 
 
+def test_empty_world(gpu, tmp_path):
+    """A world with nothing in it: every ray misses (hittable_list_hit over an empty list returns 0, hittable_list.c:125-143).  The
+    image is the background (02 / 03 integrators) or the sky gradient (01), one ray per sample; first hits are all misses; the
+    scene survives a save / load."""
+    L = gpu.lib()
+    world = L.hittable_list_new(4)
+    sc = gpu.Scene(world, None, (0.25, 0.5, 0.75))
+    cam = gpu.Camera((0, 0, 0), (0, 0, -1), (0, 1, 0), 40.0, 1.5, 0.0, 1.0)
+    path = str(tmp_path / "empty.rtcscene")
+    try:
+        assert sc.num_prims() == 0
+        for integrator in (0, 1):
+            acc, st = sc.render(cam, gpu.Settings(48, 32, 5, 10, integrator, seed=1))
+            assert st["rays"] == 48 * 32 * 5 and np.allclose(acc[..., :3], 5 * np.array([0.25, 0.5, 0.75], dtype=np.float32)) and (acc[..., 3] == 5).all()
+        sky, st = sc.render(cam, gpu.Settings(48, 32, 64, 10, 2, seed=1))
+        img = mean_image(sky)
+        assert st["rays"] == 48 * 32 * 64 and img[-1, :, 2].mean() > 0.99 and img[0, :, 0].mean() > img[-1, :, 0].mean() + 0.1   # white towards the horizon, blue above (row 0 = bottom)
+        rays = np.zeros((100, 7)); rays[:, 5] = -1
+        prim, t = sc.first_hit(rays)
+        assert (prim == -1).all()
+        sc.save(path)
+        back = gpu.Scene.load(path)
+        try:
+            again, _ = back.render(cam, gpu.Settings(48, 32, 64, 10, 2, seed=1))
+            assert np.array_equal(again, sky)
+        finally:
+            back.close()
+    finally:
+        sc.close()
+
+
 def test_full_size_mixture_weight_invariance(gpu):
     """A size-independent property at BASELINE config 2's full size (1920x1080, 256 spp, depth 10): the mixture weight of
     pdf.c:119-121 changes the variance of the estimator, never its mean -- Cornell rendered with weight 0.1 (ray.c:72), 0.5 and

@@ -533,6 +533,7 @@ void build_bleaves(FlatScene &fs) {
 // (sphere), the face flags follow hit_record_set_facenormal and the wrappers' re-facing (F11, flip_face), the colour is
 // resolved when the texture is a solid one.  Anything else -- a texture that must be evaluated, a moving sphere, a medium
 // -- is marked RTC_SF_GENERAL and goes through prims / chains / materials / textures as before.
+void chain_facing(const FlatScene &fs, int chain, bool &normal_ok, bool &front_ok, bool &flip);   // below, with its explanation
 void build_leaf_shade(FlatScene &fs) {
     fs.leaf_shade.clear();
     for (int id : fs.leaf_prims) {
@@ -541,8 +542,11 @@ void build_leaf_shade(FlatScene &fs) {
         SmallShade S; std::memset(&S, 0, sizeof S);
         double M[9], b[3]; bool wrapped, flip;
         collapse_chain(fs, p.chain, M, b, wrapped, flip);
+        bool normal_ok, front_ok;
+        chain_facing(fs, p.chain, normal_ok, front_ok, flip);
         S.meta = (uint32_t)m.type | (wrapped ? RTC_SF_FORCED_FRONT : 0u) | (flip ? RTC_SF_FLIP : 0u);
         bool general = p.type != RTC_PRIM_RECT && p.type != RTC_PRIM_SPHERE;
+        if (!normal_ok || ((m.type == RTC_MAT_DIELECTRIC || m.type == RTC_MAT_LIGHT) && !front_ok)) general = true;   // replay the chain (resolve_hit)
         if (m.type == RTC_MAT_METAL) { for (int k = 0; k < 3; k++) S.rgb[k] = (float)m.albedo[k]; S.param = (float)m.param; }
         else if (m.type == RTC_MAT_DIELECTRIC) { S.rgb[0] = S.rgb[1] = S.rgb[2] = 1.0f; S.param = (float)m.param; }
         else if (m.type == RTC_MAT_ISOTROPIC || m.tex < 0 || fs.textures[m.tex].type != RTC_TEX_SOLID) general = true;
@@ -559,6 +563,28 @@ void build_leaf_shade(FlatScene &fs) {
         if (general) S.meta |= RTC_SF_GENERAL;
         fs.leaf_shade.push_back(S);
     }
+}
+
+// Can the resolved shading record (SmallShade: a normal faced against the ray, front_face = "wrapped ? true : natural", then
+// the flip parity) stand in for resolve_hit's replay of the wrapper chain (rt_core.hpp)?  The reference re-faces the normal
+// in every wrapper (F11): translate_hit against its own ray -- which leaves a faced normal alone and sets front_face = 1 --
+// but rotate_hit against the OBJECT-space ray with the normal already turned back to the parent space, so behind a rotate
+// front_face depends on the angle, and a chain whose outermost wrapper is a rotate can even leave the normal facing along
+// the ray.  flip_face toggles front_face where it stands; a wrapper outside it sets front_face anew.
+//   normal_ok: no wrapper, or the outermost one is a translate (it re-faces last, against the true ray)
+//   front_ok : no rotate in the chain; flip = parity of the flips OUTSIDE the outermost wrapper (all of them without one)
+// Lambertian and metal shading never read front_face, so they only need normal_ok.
+void chain_facing(const FlatScene &fs, int chain, bool &normal_ok, bool &front_ok, bool &flip) {
+    const ChainRange cr = fs.chains[chain];
+    int outer = -1; bool rotate = false; flip = false;
+    for (int i = 0; i < cr.count; i++) {
+        const OpT<double> &o = fs.ops[cr.first + i];
+        if (o.type == RTC_OP_FLIP) { if (outer < 0) flip = !flip; continue; }
+        if (outer < 0) outer = i;
+        rotate |= o.type == RTC_OP_ROTATE;
+    }
+    normal_ok = outer < 0 || fs.ops[cr.first + outer].type == RTC_OP_TRANSLATE;
+    front_ok = !rotate;
 }
 
 // Small-scene pack: eligible when every leaf is a rect or a sphere, there are at most 64 of them, and every
@@ -597,6 +623,12 @@ void build_small_pack(FlatScene &fs) {
         bool wrapped, flip;
         const int x = chain_xform(p.chain, wrapped, flip);
         if ((int)xf.size() > RTC_SMALL_MAX_XFORMS) return;
+        {   // the record must answer exactly as the wrapper chain would (chain_facing); otherwise the scene takes the general kernel
+            bool normal_ok, front_ok;
+            chain_facing(fs, p.chain, normal_ok, front_ok, flip);
+            const bool reads_front = m.type == RTC_MAT_DIELECTRIC || m.type == RTC_MAT_LIGHT;
+            if (!normal_ok || (reads_front && !front_ok)) return;
+        }
         const double *M = xfd[x].data(), *b = M + 9;
         S.meta = (uint32_t)m.type | (wrapped ? RTC_SF_FORCED_FRONT : 0u) | (flip ? RTC_SF_FLIP : 0u);
         if (m.type == RTC_MAT_METAL) { for (int k = 0; k < 3; k++) S.rgb[k] = (float)m.albedo[k]; S.param = (float)m.param; any_fuzz |= m.param > 0; }

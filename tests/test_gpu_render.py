@@ -613,6 +613,115 @@ def test_empty_world(gpu, tmp_path):
         sc.close()
 
 
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
+def test_random_small_scenes_against_the_general_kernel(gpu, seed):
+    """The small-scene pack (flatten.cpp build_small_pack: object spaces, box records made of whichever rects share a box --
+    all six, or three to five --, rect pairs per axis with an odd one out, spheres) on scenes nobody designed: random boxes
+    under random rotations and translations, loose rects on all three axes (some flipped), spheres of all four materials, every
+    leaf its own colour, lit by the 01 sky.  Small-scene kernel against the general kernel (prims in visit order, one test per
+    leaf): 96x96 at 2048 spp, depth 4."""
+    rng = np.random.default_rng(seed)
+    L = gpu.lib()
+    v3 = gpu.api.v3
+
+    def colour():
+        return v3(tuple(rng.uniform(0.15, 0.9, 3)))
+
+    def material(glass_ok=True):
+        k = rng.integers(0, 10 if glass_ok else 8)
+        if k < 6: return L.material_lambertian_new_from_color(colour())
+        if k < 8: return L.material_metal_new(colour(), float(rng.choice([0.0, 0.0, 0.2])))
+        return L.material_dielectric_new(1.5)
+
+    world = L.hittable_list_new(64)
+    leaves = 0
+    L.hittable_rect_new(world, -400, 400, 0, 0, -400, 400, 0, 1, L.material_lambertian_new_from_color(colour())); leaves += 1   # a floor
+    n_boxes = int(rng.integers(2, 8))
+    for _ in range(n_boxes):
+        size = rng.uniform(40, 140, 3)
+        b = L.hittable_box_new(None, v3((0, 0, 0)), v3(tuple(size)), material(glass_ok=False))   # glass behind a rotate is not a small scene (below)
+        if rng.random() < 0.7:
+            b = L.hittable_rotate_init(None, b, float(rng.uniform(-60, 60)), int(rng.integers(0, 3)))
+        L.hittable_translate_init(world, b, v3((float(rng.uniform(-300, 200)), float(rng.uniform(0, 120)), float(rng.uniform(-300, 200)))))
+        leaves += 6
+    for _ in range(int(rng.integers(2, 7))):                                  # loose rects: open corners, pairs and odd runs
+        axis = int(rng.integers(0, 3)); a0, b0 = rng.uniform(-300, 150, 2); a1, b1 = a0 + rng.uniform(40, 200), b0 + rng.uniform(40, 200); k = float(rng.uniform(-250, 250))
+        lo = [0.0, 0.0, 0.0]; hi = [0.0, 0.0, 0.0]
+        ia, ib = ((0, 1), (0, 2), (1, 2))[axis]
+        lo[ia], hi[ia], lo[ib], hi[ib] = a0, a1, b0, b1
+        if axis == 1: k = abs(k) + 5                                          # keep XZ rects above the floor
+        r = L.hittable_rect_new(None, lo[0], hi[0], lo[1], hi[1], lo[2], hi[2], k, axis, material())
+        if rng.random() < 0.3: r = L.hittable_flip_face_init(None, r)
+        L.hittable_list_add(world, r); leaves += 1
+    for _ in range(int(rng.integers(1, 6))):
+        rad = float(rng.uniform(25, 80))
+        L.hittable_sphere_new(world, v3((float(rng.uniform(-300, 300)), rad + float(rng.uniform(0, 150)), float(rng.uniform(-300, 300)))), rad * (1 if rng.random() < 0.85 else -1), material()); leaves += 1
+    assert leaves <= 64
+    sc = gpu.Scene(world, None, (0, 0, 0))
+    cam = gpu.Camera((float(rng.uniform(-200, 200)), float(rng.uniform(250, 500)), -900.0), (0, 80, 0), (0, 1, 0), 45.0, 1.0, 0.0, 10.0)
+    try:
+        assert sc.num_prims() == leaves
+        a, sa = sc.render(cam, gpu.Settings(96, 96, 2048, 4, 2, seed=1, kernel=1))
+        b, sb = sc.render(cam, gpu.Settings(96, 96, 2048, 4, 2, seed=2, kernel=2))
+    finally:
+        sc.close()
+    assert sa["kernel_used"] == 1 and sb["kernel_used"] == 2
+    ia_, ib_ = clip01(mean_image(a)), clip01(mean_image(b))
+    blk = np.sqrt(((block_means(ia_) - block_means(ib_)) ** 2).mean(axis=(0, 1)))
+    worst = np.abs(block_means(ia_) - block_means(ib_)).max()
+    la, lb = (ia_ @ LUMA).mean(), (ib_ @ LUMA).mean()
+    print(f"random scene {seed}: {leaves} leaves, {n_boxes} boxes: blk4 {blk.round(5)} worst block {worst:.4f} dlum {abs(la - lb) / lb:.5f} rays/sample {sa['rays'] / sa['samples']:.4f} vs {sb['rays'] / sb['samples']:.4f}")
+    assert blk.max() <= 0.003 and worst <= 0.015 and abs(la - lb) / lb <= 0.003
+    assert abs(sa["rays"] / sa["samples"] - sb["rays"] / sb["samples"]) <= 0.003 * sa["rays"] / sa["samples"]
+
+
+def test_front_face_behind_wrappers(gpu):
+    """F11: the reference re-faces the normal in every wrapper -- rotate_hit against the OBJECT-space ray with the normal already
+    turned back (hittable.c:552-557), translate_hit against its own ray (:533-534) -- so behind a rotate front_face depends on the
+    angle, a chain that ends in a rotate can leave the normal facing along the ray, and a flip_face inside a wrapper is undone by
+    it.  Glass and lamps read front_face.  The general kernel replays the chain (rt_core.hpp resolve_hit, pinned bit for bit by
+    the first-hit tests); the resolved shading records of the small-scene kernel and of the wavefront shade stage may stand in
+    only where they give the same answer (flatten.cpp chain_facing).  A rotated glass box, a box whose outermost wrapper is a
+    rotate, and a lamp flipped inside a translate: not a small scene; as a BVH scene the wavefront kernels agree with the megakernel."""
+    L = gpu.lib()
+    v3 = gpu.api.v3
+
+    def build(pad):
+        world = L.hittable_list_new(128)
+        lights = L.hittable_list_new_no_gc(2)
+        white = L.material_lambertian_new_from_color(v3((0.73, 0.73, 0.73)))
+        L.hittable_rect_new(world, -400, 400, 0, 0, -400, 400, 0, 1, white)
+        glass_box = L.hittable_rotate_init(None, L.hittable_box_new(None, v3((0, 0, 0)), v3((120, 160, 100)), L.material_dielectric_new(1.5)), 52.0, 2)
+        L.hittable_translate_init(world, glass_box, v3((-150, 40, 0)))
+        turned = L.hittable_translate_init(None, L.hittable_box_new(None, v3((0, 0, 0)), v3((100, 100, 100)), L.material_metal_new(v3((0.8, 0.8, 0.8)), 0.0)), v3((100, 0, 50)))
+        L.hittable_rotate_init(world, turned, 35.0, 1)                                        # the rotate is the OUTERMOST wrapper
+        lamp = L.hittable_rect_new(None, -100, 100, 0, 0, -100, 100, 0, 1, L.material_light_new_from_color(v3((6, 6, 6))))
+        L.hittable_translate_init(world, L.hittable_flip_face_init(None, lamp), v3((0, 400, 0)))   # the flip is INSIDE the translate
+        for i in range(pad):
+            L.hittable_sphere_new(world, v3((1e6 + 10 * i, 1e6, 1e6)), 0.5, white)
+        return gpu.Scene(world, lights, (0.05, 0.05, 0.08))
+
+    cam = gpu.Camera((0, 350, -900), (0, 80, 0), (0, 1, 0), 45.0, 1.0, 0.0, 10.0)
+    plain, padded = build(0), build(80)
+    try:
+        assert plain.bvh_info()["nodes"] == 0 and padded.bvh_info()["nodes"] > 0
+        with pytest.raises(gpu.RtcError):
+            plain.render(cam, gpu.Settings(16, 16, 1, 8, 1, kernel=2))
+        a, sa = plain.render(cam, gpu.Settings(96, 96, 1024, 8, 1, seed=3))
+        b, sb = padded.render(cam, gpu.Settings(96, 96, 1024, 8, 1, seed=3))
+        c, sc3 = padded.render(cam, gpu.Settings(96, 96, 1024, 8, 0, seed=3))                 # the 03 integrator reads the lamp's front_face
+        d, sd = padded.render(cam, gpu.Settings(96, 96, 1024, 8, 0, seed=3, kernel=1))
+    finally:
+        plain.close(); padded.close()
+    assert sa["kernel_used"] == 1 and sb["kernel_used"] == 3 and sc3["kernel_used"] == 3 and sd["kernel_used"] == 1
+    for x, y, what in ((a, b, "02 integrator"), (d, c, "03 integrator")):
+        ix, iy = clip01(mean_image(x)), clip01(mean_image(y))
+        blk = np.sqrt(((block_means(ix) - block_means(iy)) ** 2).mean(axis=(0, 1)))
+        print(f"front_face behind wrappers, {what}: blk4 {blk.round(5)} mean {ix.mean():.4f}")
+        assert blk.max() <= 0.001 and ix.mean() > 0.02
+    assert abs(sa["rays"] - sb["rays"]) <= 0.005 * sa["rays"] and abs(sc3["rays"] - sd["rays"]) <= 0.005 * sd["rays"]
+
+
 def test_full_size_mixture_weight_invariance(gpu):
     """A size-independent property at BASELINE config 2's full size (1920x1080, 256 spp, depth 10): the mixture weight of
     pdf.c:119-121 changes the variance of the estimator, never its mean -- Cornell rendered with weight 0.1 (ray.c:72), 0.5 and

@@ -675,6 +675,74 @@ def test_random_small_scenes_against_the_general_kernel(gpu, seed):
     assert abs(sa["rays"] / sa["samples"] - sb["rays"] / sb["samples"]) <= 0.003 * sa["rays"] / sa["samples"]
 
 
+@pytest.mark.parametrize("seed", [11, 12, 13, 14])
+def test_random_bvh_scenes_wavefront_against_megakernel(gpu, seed):
+    """The wavefront pipeline (BVH traversal with box records, world-space quads, resolved or replayed shading records, media in
+    the leaves) against the megakernel (same tree, chain replay for every hit) on scenes nobody designed: 70-130 leaves of random
+    boxes -- glass ones too -- under random wrapper chains (rotate inside or outside the translate, flips), loose rects, spheres,
+    moving spheres, a sphere-bounded and a box-bounded medium.  Same Philox keys: the images agree to the order of the sums."""
+    rng = np.random.default_rng(seed)
+    L = gpu.lib()
+    v3 = gpu.api.v3
+    colour = lambda: v3(tuple(rng.uniform(0.15, 0.9, 3)))
+
+    def material():
+        k = rng.integers(0, 10)
+        if k < 5: return L.material_lambertian_new_from_color(colour())
+        if k < 7: return L.material_metal_new(colour(), float(rng.choice([0.0, 0.2])))
+        if k < 9: return L.material_dielectric_new(1.5)
+        return L.material_light_new_from_color(v3((3, 3, 3)))
+
+    world = L.hittable_list_new(256)
+    L.hittable_rect_new(world, -500, 500, 0, 0, -500, 500, 0, 1, L.material_lambertian_new_from_color(colour()))
+    for _ in range(int(rng.integers(9, 17))):
+        b = L.hittable_box_new(None, v3((0, 0, 0)), v3(tuple(rng.uniform(30, 110, 3))), material())
+        off = v3((float(rng.uniform(-400, 300)), float(rng.uniform(0, 150)), float(rng.uniform(-400, 300))))
+        how = rng.integers(0, 4)
+        if how == 0: b = L.hittable_translate_init(None, b, off)                                                        # axis-aligned: a box record
+        elif how == 1: b = L.hittable_translate_init(None, L.hittable_rotate_init(None, b, float(rng.uniform(-70, 70)), int(rng.integers(0, 3))), off)
+        elif how == 2: b = L.hittable_rotate_init(None, L.hittable_translate_init(None, b, off), float(rng.uniform(-25, 25)), 1)   # rotate outermost
+        else: b = L.hittable_flip_face_init(None, L.hittable_translate_init(None, L.hittable_flip_face_init(None, b), off))  # flips inside and outside
+        L.hittable_list_add(world, b)
+    for _ in range(int(rng.integers(4, 10))):
+        axis = int(rng.integers(0, 3)); a0, b0 = rng.uniform(-400, 250, 2); a1, b1 = a0 + rng.uniform(40, 200), b0 + rng.uniform(40, 200)
+        lo = [0.0, 0.0, 0.0]; hi = [0.0, 0.0, 0.0]; ia, ib = ((0, 1), (0, 2), (1, 2))[axis]
+        lo[ia], hi[ia], lo[ib], hi[ib] = a0, a1, b0, b1
+        L.hittable_rect_new(world, lo[0], hi[0], lo[1], hi[1], lo[2], hi[2], float(abs(rng.uniform(-250, 250)) + 5), axis, material())
+    for _ in range(int(rng.integers(6, 14))):
+        rad = float(rng.uniform(20, 70)); c = (float(rng.uniform(-400, 400)), rad + float(rng.uniform(0, 200)), float(rng.uniform(-400, 400)))
+        if rng.random() < 0.3: L.hittable_moving_sphere_new(world, v3(c), v3((c[0] + 30, c[1] + 20, c[2])), 0.0, 1.0, rad, material())
+        else: L.hittable_sphere_new(world, v3(c), rad, material())
+    L.hittable_constant_medium_init_c(world, L.hittable_sphere_new(None, v3((100, 150, 100)), 120.0, L.material_dielectric_new(1.5)), 0.01, v3((0.9, 0.9, 1.0)))
+    fog = L.hittable_translate_init(None, L.hittable_rotate_init(None, L.hittable_box_new(None, v3((0, 0, 0)), v3((150, 150, 150)), L.material_dielectric_new(1.5)), 25.0, 1), v3((-250, 20, -100)))
+    L.hittable_constant_medium_init_c(world, fog, 0.008, v3((0.2, 0.2, 0.2)))
+    sc = gpu.Scene(world, None, (0.35, 0.4, 0.5), 0.0, 1.0)
+    cam = gpu.Camera((float(rng.uniform(-200, 200)), float(rng.uniform(300, 600)), -1100.0), (0, 80, 0), (0, 1, 0), 45.0, 1.0, 0.0, 10.0, 0.0, 1.0)
+    try:
+        n = sc.num_prims()
+        assert n > 64 and sc.bvh_info()["nodes"] > 0
+        a, sa = sc.render(cam, gpu.Settings(96, 96, 256, 6, 1, seed=7, kernel=1))
+        b, sb = sc.render(cam, gpu.Settings(96, 96, 256, 6, 1, seed=7, kernel=3))
+        # and the tree itself against the reference's own traversal (FP64 check kernel: list scan, no production BVH), from inside the scene
+        rays = np.zeros((20000, 7)); rays[:, :3] = (0.0, 260.0, 0.0) + rng.uniform(-150, 150, (20000, 3)); rays[:, 3:6] = rng.normal(size=(20000, 3)); rays[:, 6] = rng.random(20000)
+        rays = rays.astype(np.float32).astype(np.float64)
+        p64, t64 = sc.first_hit(rays)
+        p32, t32 = sc.first_hit_f32(rays)
+    finally:
+        sc.close()
+    same = p32 == p64
+    both = same & (p64 >= 0)
+    err = np.abs(t32[both] - t64[both]) / np.maximum(1.0, t64[both])
+    print(f"random BVH scene {seed}: FP32 tree vs FP64 list scan: same primitive {same.mean():.5f}, t error p99 {np.quantile(err, 0.99):.1e} max {err.max():.1e}")
+    assert same.mean() >= 0.995 and both.sum() > 5000 and np.quantile(err, 0.99) <= 2e-4 and err.max() <= 1e-2
+    assert sa["kernel_used"] == 1 and sb["kernel_used"] == 3
+    ia_, ib_ = clip01(mean_image(a)), clip01(mean_image(b))
+    blk = np.sqrt(((block_means(ia_) - block_means(ib_)) ** 2).mean(axis=(0, 1)))
+    worst = np.abs(block_means(ia_) - block_means(ib_)).max()
+    print(f"random BVH scene {seed}: {n} leaves: blk4 {blk.round(5)} worst block {worst:.4f} rays {sa['rays']} vs {sb['rays']}")
+    assert blk.max() <= 0.001 and worst <= 0.01 and abs(sa["rays"] - sb["rays"]) <= 0.005 * sa["rays"]
+
+
 def test_front_face_behind_wrappers(gpu):
     """F11: the reference re-faces the normal in every wrapper -- rotate_hit against the OBJECT-space ray with the normal already
     turned back (hittable.c:552-557), translate_hit against its own ray (:533-534) -- so behind a rotate front_face depends on the

@@ -613,8 +613,8 @@ def test_empty_world(gpu, tmp_path):
         sc.close()
 
 
-@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
-def test_random_small_scenes_against_the_general_kernel(gpu, seed):
+@pytest.mark.parametrize("seed,integrator", [(1, 2), (2, 2), (3, 2), (4, 2), (5, 2), (6, 2), (7, 0), (8, 0), (9, 0)])
+def test_random_small_scenes_against_the_general_kernel(gpu, seed, integrator):
     """The small-scene pack (flatten.cpp build_small_pack: object spaces, box records made of whichever rects share a box --
     all six, or three to five --, rect pairs per axis with an odd one out, spheres) on scenes nobody designed: random boxes
     under random rotations and translations, loose rects on all three axes (some flipped), spheres of all four materials, every
@@ -656,13 +656,21 @@ def test_random_small_scenes_against_the_general_kernel(gpu, seed):
     for _ in range(int(rng.integers(1, 6))):
         rad = float(rng.uniform(25, 80))
         L.hittable_sphere_new(world, v3((float(rng.uniform(-300, 300)), rad + float(rng.uniform(0, 150)), float(rng.uniform(-300, 300)))), rad * (1 if rng.random() < 0.85 else -1), material()); leaves += 1
+    lights = None
+    if integrator == 0:                                                       # the 03 integrator: a lamp over the scene and a light list of lamp + one sphere
+        lights = L.hittable_list_new_no_gc(4)
+        lamp = L.hittable_rect_new(None, -250, 250, 0, 0, -250, 250, 650, 1, L.material_light_new_from_color(v3((5, 5, 5))))
+        L.hittable_flip_face_init(world, lamp); L.hittable_list_add(lights, lamp); leaves += 1
+        ball = L.hittable_sphere_new(world, v3((float(rng.uniform(-200, 200)), 300.0, float(rng.uniform(-200, 200)))), 60.0, L.material_dielectric_new(1.5))
+        L.hittable_list_add(lights, ball); leaves += 1
     assert leaves <= 64
-    sc = gpu.Scene(world, None, (0, 0, 0))
+    sc = gpu.Scene(world, lights, (0, 0, 0))
     cam = gpu.Camera((float(rng.uniform(-200, 200)), float(rng.uniform(250, 500)), -900.0), (0, 80, 0), (0, 1, 0), 45.0, 1.0, 0.0, 10.0)
+    spp, depth = (2048, 4) if integrator == 2 else (8192, 6)
     try:
         assert sc.num_prims() == leaves
-        a, sa = sc.render(cam, gpu.Settings(96, 96, 2048, 4, 2, seed=1, kernel=1))
-        b, sb = sc.render(cam, gpu.Settings(96, 96, 2048, 4, 2, seed=2, kernel=2))
+        a, sa = sc.render(cam, gpu.Settings(96, 96, spp, depth, integrator, seed=1, kernel=1))
+        b, sb = sc.render(cam, gpu.Settings(96, 96, spp, depth, integrator, seed=2, kernel=2))
     finally:
         sc.close()
     assert sa["kernel_used"] == 1 and sb["kernel_used"] == 2
@@ -671,7 +679,8 @@ def test_random_small_scenes_against_the_general_kernel(gpu, seed):
     worst = np.abs(block_means(ia_) - block_means(ib_)).max()
     la, lb = (ia_ @ LUMA).mean(), (ib_ @ LUMA).mean()
     print(f"random scene {seed}: {leaves} leaves, {n_boxes} boxes: blk4 {blk.round(5)} worst block {worst:.4f} dlum {abs(la - lb) / lb:.5f} rays/sample {sa['rays'] / sa['samples']:.4f} vs {sb['rays'] / sb['samples']:.4f}")
-    assert blk.max() <= 0.003 and worst <= 0.015 and abs(la - lb) / lb <= 0.003
+    tol_blk, tol_worst = (0.003, 0.015) if integrator == 2 else (0.006, 0.05)      # a lamp through glass and mirrors: fireflies in single blocks
+    assert blk.max() <= tol_blk and worst <= tol_worst and abs(la - lb) / lb <= 0.005
     assert abs(sa["rays"] / sa["samples"] - sb["rays"] / sb["samples"]) <= 0.003 * sa["rays"] / sa["samples"]
 
 

@@ -139,10 +139,13 @@ def main():
         if rank == 0:
             rc = ra.lib().rtc_tonemap_u8_device(accum.data_ptr(), WIDTH, HEIGHT, rgb8.data_ptr(), stream)
             assert rc == 0
-        if record:
-            st = scene.stats(stream)                             # waits for the render kernel's end event
+        # Reading the counters waits for the render kernel's end event (a host sync).  At N = 1 that is every step -- the
+        # roofline's kernel time is the average over the timed launches; at N > 1 a sync per step would stop rank r from
+        # enqueueing its next render while the reduce of this one is in flight, so only the last timed step is read.
+        if record and (world == 1 or i == a.warmup + a.steps - 1):
+            st = scene.stats(stream)
             kernel_ms.append(st["kernel_ms"])
-            rays_total += st["rays"]
+            rays_total += st["rays"] * (1 if world == 1 else a.steps)   # every step traces the same number of paths +- the sample range
             kernel_used[0], lane_fill[0] = st["kernel_used"], st["lane_fill"]
 
     def fence():

@@ -63,6 +63,7 @@ texture *texture_noise_init_scaled(double sc); /* builds the perlin tables with 
 texture *texture_noise_init(void);
 texture *texture_image_init(char *filename);   /* baseline JPEG or binary PPM (P6); NULL + message on failure like texture.c:67 */
 texture *texture_image_init_rgb(const unsigned char *rgb, int width, int height); /* extension: decoded pixels */
+void     texture_free(texture *t);              /* texture.h:65; also clears the registry slot (the reference leaves it dangling) */
 void     textures_free_all(void);
 
 /* ---- materials (03_FullTracer/material.h:39-52) */
@@ -74,6 +75,7 @@ material *material_light_new(texture *t);
 material *material_light_new_from_color(color c);
 material *material_isotropic_new(texture *t);
 material *material_isotropic_new_from_color(color c);
+void      material_free(material *m);           /* material.h:47; also clears the registry slot */
 void      materials_free_all(void);
 
 /* ---- lists (03_FullTracer/hittable_list.h:29-41) */
@@ -106,8 +108,20 @@ void      hittable_free(hittable *o);
 camera *camera_new(point3 lookfrom, point3 lookat, vec3 vup, double vfov, double aspect_ratio, double aperture,
                    double focus_dist, double time0, double time1);
 void    camera_free(camera *c);
+/* camera.h:35 / camera.c:46-53: one primary ray on the host, lens sample and ray time drawn from rand() like the
+ * reference (F13).  The renderer generates its primary rays on the device; this is for callers that want single rays. */
+ray     camera_get_ray(camera *c, double s, double t);
 /* origin, lower_left_corner, horizontal, vertical, u, v, w (7 x 3), lens_radius, time0, time1 = 24 doubles */
 void    camera_fields(const camera *c, double out[24]);
+
+/* ---- the integrator's host-visible ends (03_FullTracer/ray.h:36-39)
+ * write_color: ray.c:35-47 on the host, bytes identical to the reference's (NaN -> 0 instead of undefined behaviour).
+ * ray_color:   ray.c:50-84.  ONE sample of the estimator for ONE ray, traced on the GPU (rtc_ray_colors, include/rtc.h):
+ *              the scene tables of (world, lights, background) are built on the first call and kept until another
+ *              world / lights / list length / background is passed; rand() is replaced by a Philox stream that advances
+ *              with every call.  Returns (0,0,0) and prints rtc_last_error() when no GPU is usable: there is no CPU path. */
+void  write_color(unsigned char *pixels, color *pixel_color, int samples_per_pixel, int index);
+color ray_color(ray *r, color *background, hittable_list *world, hittable_list *lights, int recursion_depth);
 
 /* ---- named scenes (raytracer_amd/csrc/host/scenes.c) */
 typedef struct rt_scene_view {

@@ -128,6 +128,29 @@ int rtc_render(const rtc_scene *scene, const camera *cam, const rtc_settings *se
 /* Blocks until the last rtc_render_device on `stream` has finished and fills the counters. */
 int rtc_render_stats(const rtc_scene *scene, void *stream, rtc_stats *out);
 
+/* ray_color (ray.c:50-84; integrator 1: 02 main.c:44-63; 2: 01 main.c:39-65) for n rays the CALLER supplies (7 doubles
+ * each: orig, dir, time) instead of the camera's: rgb_sum[3 i ..] += the estimator of ray i summed over samples
+ * [sample_begin, sample_end) -- divide by the sample count for the mean.  Of `settings` only max_depth, the sample range,
+ * integrator, seed and mixture_light_weight are read; the Philox stream is keyed on (ray index, sample, bounce).  Runs the
+ * general bounce loop (the one kernel = 1 renders with) on the current device; the host ray_color of raytracer.h is this
+ * call with n = 1 and one sample. */
+int rtc_ray_colors(const rtc_scene *scene, const double *rays7, size_t n, const rtc_settings *settings, double *rgb_sum);
+
+/* TEST-ONLY known-answer probe: evaluates, on the device and for n supplied inputs, the functions the production kernels
+ * call, so that they can be compared with the reference's outputs for the same inputs (tests/golden/unit_vectors.npz).
+ * Doubles in and out (converted to the kernels' FP32 on the device).  `what`:
+ *   0 Philox4x32-7 block of (pixel, sample, tag, key lo, key hi)  -> 4 raw words          (replaces rand(), utils.h:23)
+ *   1 light-list pdf, general kernels: origin(3) dir(3) -> pdf       (hittable_list.c:165-172, hittable.c:760-788)
+ *   2 the same as the small-scene kernel computes it (unit direction, folded hit tests)
+ *   3 cosine pdf = lambertian scattering pdf: normal(3) dir(3) -> pdf (pdf.c:100-103, material.c:205-208)
+ *   4 reflectance: cosine, ref_idx -> r                               (material.c:142)
+ *   5 refract: uv(3) n(3) eta -> dir(3)                               (vec3.c:44-50)
+ *   6 light sample, general kernels: origin(3) pick r1 r2 -> dir(3)   (hittable.c:821-848; the reference draws r1, r2 from rand())
+ *   7 the same, small-scene kernel (a basis of its own around the cone axis: same law, other azimuth)
+ *   8 glass direction, general kernels: dir(3) n(3) front_face ir xi -> dir(3)   (material.c:144-157; xi replaces random_double())
+ *   9 the same, small-scene kernel (takes the direction normalised) */
+int rtc_kat(const rtc_scene *scene, int what, const double *in, size_t n, double *out);
+
 /* write_color (ray.c:35-47): rgb/count -> sqrt -> clamp [0,0.999] -> *256 -> u8, for every pixel, on device.
  * rgb_u8 is W*H*3, same row order as accum (flip at PNG time like main.c:170).  NaN and negative sums map to 0
  * (the reference casts NaN to unsigned char: undefined, F16); +inf clamps to 255 like any large value. */

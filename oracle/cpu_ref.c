@@ -916,3 +916,29 @@ void orc_render_refloop_u8(hittable_list *world, hittable_list *lights, camera *
             }
         }
 }
+/* 01 main.c:30-35: average, gamma 2, clamp, x256, printed as decimal text */
+void orc_write_color_ppm(FILE *f, color *pc, int spp) {
+    double scale = 1.0 / (double)spp;
+    double r = sqrt(scale * pc->x), g = sqrt(scale * pc->y), b = sqrt(scale * pc->z);
+    fprintf(f, "%d %d %d\n", (int)(256 * clamp(r, 0.0, 0.999)), (int)(256 * clamp(g, 0.0, 0.999)), (int)(256 * clamp(b, 0.0, 0.999)));
+}
+/* 01 main.c:168-191: header, then rows from the top, samples in order, the rand() stream is NOT reseeded */
+int orc_render_ppm01(hittable_list *world, camera *cam, const orc_settings *st, int W, int H, int spp, const char *path) {
+    FILE *f = fopen(path, "w+");
+    if (!f) return -1;
+    orc_rng_mode(ORC_RNG_GLIBC);
+    fprintf(f, "P3\n%d %d\n255\n", W, H);
+    for (int j = H - 1; j >= 0; --j)
+        for (int i = 0; i < W; ++i) {
+            color pc = V(0, 0, 0);
+            for (int s = 0; s < spp; ++s) {
+                double u = ((double)i + random_double()) / (double)(W - 1);
+                double v = ((double)j + random_double()) / (double)(H - 1);
+                ray r = camera_get_ray(cam, u, v);
+                pc = vadd(pc, orc_ray_color(&r, st, world, NULL, st->max_depth));
+            }
+            orc_write_color_ppm(f, &pc, spp);
+        }
+    fclose(f);
+    return 0;
+}

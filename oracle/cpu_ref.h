@@ -28,6 +28,7 @@
 
 #include <stddef.h>
 #include <stdint.h>
+#include <stdio.h>
 
 #ifdef __cplusplus
 extern "C" {
@@ -230,6 +231,10 @@ int orc_render(hittable_list *world, hittable_list *lights, camera *cam, const o
 
 /* The reference's own loop order (16 row chunks, rows descending inside a chunk,
  * main.c:132-160) with rand(): byte-identical 8-bit output to the reference run single-threaded. */
+/* 01_BasicTracer's output edge: write_color(FILE*, ...) (01 main.c:30-35) and the serial loop that feeds it, rows top to
+ * bottom, one rand() stream continued from wherever it stands (01 main.c:168-191) */
+void orc_write_color_ppm(FILE *f, color *pixel_color, int samples_per_pixel);
+int  orc_render_ppm01(hittable_list *world, camera *cam, const orc_settings *st, int W, int H, int spp, const char *path);
 void orc_render_refloop_u8(hittable_list *world, hittable_list *lights, camera *cam, const orc_settings *st,
                            int width, int height, int spp, unsigned char *pixels);
 

@@ -427,6 +427,20 @@ int hx_oracle_render(int W, int H, int s_begin, int s_end, int depth, int rng_mo
     if (stats3) { stats3[0] = (double)rs.samples; stats3[1] = (double)rs.rays; stats3[2] = rs.seconds; }
     return rc;
 }
+/* 01's output edge (stage 1): the serial loop of 01 main.c:168-191 into an ASCII PPM; reseed = 0 continues the rand()
+ * stream where scene construction left it, as the reference's main() does */
+int hx_render_ppm01(const char *path, int W, int H, int spp, int depth, int reseed, unsigned seed) {
+    if (reseed) hx_srand(seed);
+    orc_settings st = settings_from_view(depth, 0);
+    return orc_render_ppm01(g_world, g_cam, &st, W, H, spp, path);
+}
+int hx_write_colors_ppm(const char *path, int n, const double *rgb3, int spp) {
+    FILE *f = fopen(path, "w+");
+    if (!f) return -1;
+    for (int i = 0; i < n; i++) { color c = {rgb3[3 * i], rgb3[3 * i + 1], rgb3[3 * i + 2]}; orc_write_color_ppm(f, &c, spp); }
+    fclose(f);
+    return 0;
+}
 int hx_ray_colors_iter(unsigned seed, int n, const double *rays7, int depth, double *rgb) {
     hx_srand(seed);
     orc_settings st = settings_from_view(depth, 0);

@@ -67,10 +67,10 @@ material_isotropic_new_from_color materials_free_all hittable_list_new hittable_
 hittable_list_index hittable_list_objects hittable_list_free hittable_lists_free_all hittable_sphere_new
 hittable_rect_new hittable_box_new hittable_moving_sphere_new bvh_node_init hittable_translate_init
 hittable_rotate_init hittable_constant_medium_init hittable_constant_medium_init_c hittable_flip_face_init
-hittable_free camera_new camera_free camera_fields rt_scene_build rt_scene_set_image_path rt_write_png rt_write_ppm_p3""".split()
+hittable_free camera_new camera_free camera_fields camera_get_ray write_color ray_color material_free texture_free rt_scene_build rt_scene_set_image_path rt_write_png rt_write_ppm_p3""".split()
 RTC_SYMBOLS = """rtc_init rtc_last_error rtc_device_name rtc_scene_build rtc_scene_flatten_only rtc_scene_save rtc_scene_load rtc_scene_load_host rtc_scene_free rtc_scene_num_prims
 rtc_scene_dump_leaves rtc_scene_bvh_info rtc_scene_dump_bvh rtc_first_hit_f64 rtc_first_hit_f32 rtc_primary_first_hit_f64 rtc_render_device rtc_render rtc_render_stats
-rtc_tonemap_u8_device rtc_tonemap_u8 make_scene free_scene render_scene render_scene_accumulate""".split()
+rtc_tonemap_u8_device rtc_tonemap_u8 rtc_ray_colors rtc_kat make_scene free_scene render_scene render_scene_accumulate""".split()
 
 
 def lib():
@@ -150,6 +150,14 @@ def lib():
     L.rtc_render_stats.argtypes = [_P, _P, C.POINTER(RtcStats)]
     L.rtc_tonemap_u8_device.argtypes = [_P, C.c_int, C.c_int, _P, _P]
     L.rtc_tonemap_u8.argtypes = [_P, C.c_int, C.c_int, _P]
+    L.rtc_ray_colors.argtypes = [_P, _dp, C.c_size_t, C.POINTER(RtcSettings), _dp]
+    L.rtc_kat.argtypes = [_P, C.c_int, _dp, C.c_size_t, _dp]
+    L.write_color.argtypes = [_P, C.POINTER(Vec3), C.c_int, C.c_int]
+    L.write_color.restype = None
+    L.ray_color.argtypes = [_P, C.POINTER(Vec3), _P, _P, C.c_int]
+    L.ray_color.restype = Vec3
+    L.material_free.argtypes = [_P]
+    L.texture_free.argtypes = [_P]
     L.make_scene.restype = _P
     L.make_scene.argtypes = [_P, _P, C.c_int]
     L.free_scene.argtypes = [_P]
@@ -291,6 +299,25 @@ class Scene:
             accum = np.zeros((s.height, s.width, 4), dtype=np.float32)
         _check(lib().rtc_render(self.handle, cam.handle, C.byref(s), accum.ctypes.data), "rtc_render")
         return accum, self.stats(None)
+
+    def ray_colors(self, rays7, settings, rgb_sum=None):
+        """rtc_ray_colors: the estimator of each supplied ray summed over the settings' sample range -> (n, 3) float64."""
+        rays7 = np.ascontiguousarray(rays7, dtype=np.float64)
+        n = rays7.size // 7
+        if rgb_sum is None:
+            rgb_sum = np.zeros((n, 3))
+        _check(lib().rtc_ray_colors(self.handle, rays7.ctypes.data_as(_dp), n, C.byref(settings.c), rgb_sum.ctypes.data_as(_dp)), "rtc_ray_colors")
+        return rgb_sum
+
+    def kat(self, what, inputs):
+        """rtc_kat: device functions on supplied inputs (test-only); `what` as in include/rtc.h."""
+        stride_in = (5, 6, 6, 6, 2, 7, 6, 6, 9, 9)[what]
+        stride_out = (4, 1, 1, 1, 1, 3, 3, 3, 3, 3)[what]
+        inputs = np.ascontiguousarray(inputs, dtype=np.float64)
+        n = inputs.size // stride_in
+        out = np.zeros((n, stride_out))
+        _check(lib().rtc_kat(self.handle, what, inputs.ctypes.data_as(_dp), n, out.ctypes.data_as(_dp)), "rtc_kat")
+        return out[:, 0] if stride_out == 1 else out
 
     def render_device(self, cam, settings, accum_ptr, stream=None):
         _check(lib().rtc_render_device(self.handle, cam.handle, C.byref(settings.c), accum_ptr, stream), "rtc_render_device")

@@ -65,6 +65,9 @@ RT_DEV f3 uniform_sphere(float a, float b) {             // same law as vec3_ran
     return f3mk(s * cos2pi(b), s * sin2pi(b), z);
 }
 
+// pdf_cosine_value (pdf.c:100-103) == material_lambertian_scattering_pdf (material.c:205-208) for UNIT n and direction
+RT_DEV float lambert_pdf(f3 n, f3 udir) { const float c = dot(n, udir); return c > 0.0f ? c * RT_INV_PI : 0.0f; }
+
 struct Onb { f3 u, v, w; };
 RT_DEV Onb onb_from_w(f3 n) {                            // onb.c:7-12
     Onb o; o.w = normalize(n);
@@ -328,12 +331,10 @@ RT_DEV int shade_hit_mat(const SceneT<float> &sc, PathState &ps, const RecT<floa
         dir = onb_local(uvw, f3mk(cos2pi(xi.z) * sr, sin2pi(xi.z) * sr, __builtin_amdgcn_sqrtf(1.0f - r2)));
     }
     const f3 udir = normalize(dir);
-    const float cosw = dot(udir, uvw.w);
-    const float pdf_cos = cosw <= 0.0f ? 0.0f : cosw * RT_INV_PI;                       // pdf.c:100-103
+    const float pdf_cos = lambert_pdf(uvw.w, udir);                                     // pdf.c:100-103
     const float pdf_light = sc.n_lights > 0 ? light_list_pdf(sc, rec.p, dir) : 0.0f;
     const float pdf_val = light_weight * pdf_light + (1.0f - light_weight) * pdf_cos;   // pdf.c:119-121
-    const float cosn = dot(rec.n, udir);
-    const float spdf = cosn < 0.0f ? 0.0f : cosn * RT_INV_PI;                           // material.c:205-208
+    const float spdf = lambert_pdf(rec.n, udir);                                        // material.c:205-208
     // spdf == 0: the reference keeps recursing but multiplies the child by 0; pdf_val == 0: 0/0 = NaN in the
     // reference (scrubbed to a black sample).  Either way nothing more can reach the pixel.
     if (!(spdf > 0.0f) || !(pdf_val > 0.0f)) return RT_TERMINATE;

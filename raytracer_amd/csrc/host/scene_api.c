@@ -68,6 +68,26 @@ texture *texture_image_init_rgb(const unsigned char *rgb, int width, int height)
     t->pixels = (unsigned char *)malloc((size_t)width * height * 3); memcpy(t->pixels, rgb, (size_t)width * height * 3);
     return t;
 }
+/* "P6 <width> <height> <maxval><one whitespace byte>" read from a buffer of n bytes that is NOT NUL-terminated (a file image):
+ * a bounded scanner instead of sscanf, which runs strlen over its input first.  '#' comments run to the end of the line. */
+static int ppm_header(const unsigned char *p, size_t n, int *w, int *h, int *maxval, size_t *data_offset) {
+    size_t i = 2;
+    int *field[3] = {w, h, maxval};
+    for (int k = 0; k < 3; k++) {
+        for (;;) {   /* whitespace and comments before the number */
+            while (i < n && (p[i] == ' ' || p[i] == '\t' || p[i] == '\n' || p[i] == '\r' || p[i] == '\v' || p[i] == '\f')) i++;
+            if (i < n && p[i] == '#') { while (i < n && p[i] != '\n') i++; continue; }
+            break;
+        }
+        long v = 0; int digits = 0;
+        while (i < n && p[i] >= '0' && p[i] <= '9' && digits < 9) { v = v * 10 + (p[i] - '0'); i++; digits++; }
+        if (digits == 0 || (i < n && p[i] >= '0' && p[i] <= '9')) return 0;   /* no number, or more than 9 digits */
+        *field[k] = (int)v;
+    }
+    if (i >= n || !(p[i] == ' ' || p[i] == '\t' || p[i] == '\n' || p[i] == '\r')) return 0;   /* the single separator before the samples */
+    *data_offset = i + 1;
+    return 1;
+}
 /* texture.c:63-70 loads through stb_image; here: baseline JPEG (jpeg_decode.c) and binary PPM (P6, maxval 255), told apart
  * by their magic bytes.  NULL + the reference's message on failure. */
 texture *texture_image_init(char *filename) {
@@ -80,10 +100,10 @@ texture *texture_image_init(char *filename) {
         if (size > 3 && file[0] == 0xFF && file[1] == 0xD8) {
             if (rt_jpeg_decode(file, (size_t)size, &w, &h, &rgb)) t = texture_image_init_rgb(rgb, w, h);
         } else if (size > 8 && file[0] == 'P' && file[1] == '6') {
-            int mx = 0, used = 0;
-            if (sscanf((const char *)file, "P6 %d %d %d%n", &w, &h, &mx, &used) == 3 && mx == 255 && w > 0 && h > 0
-                && (size_t)used + 1 + (size_t)w * h * 3 <= (size_t)size)
-                t = texture_image_init_rgb(file + used + 1, w, h);
+            int mx = 0; size_t data = 0;
+            if (ppm_header(file, (size_t)size, &w, &h, &mx, &data) && mx == 255 && w > 0 && h > 0
+                && (size_t)w * (size_t)h * 3 <= (size_t)size - data)
+                t = texture_image_init_rgb(file + data, w, h);
         }
     }
     if (f) fclose(f);
@@ -91,8 +111,15 @@ texture *texture_image_init(char *filename) {
     if (!t) { printf("!! could not load texture image file '%s'! \n", filename ? filename : "(null)"); fflush(stdout); }
     return t;
 }
+/* texture.c:76-90 frees one texture and leaves its pointer in the registry (a later textures_free_all would free it twice);
+ * here the slot is cleared.  A checker does not own its two sub-textures: they are registered on their own. */
+void texture_free(texture *t) {
+    if (!t) return;
+    if (t->id >= 0 && t->id < g_textures.n && g_textures.v[t->id] == t) g_textures.v[t->id] = NULL;
+    free(t->ranvec); free(t->perm); free(t->pixels); free(t);
+}
 void textures_free_all(void) {
-    for (int i = 0; i < g_textures.n; i++) { texture *t = (texture *)g_textures.v[i]; free(t->ranvec); free(t->perm); free(t->pixels); free(t); }
+    for (int i = 0; i < g_textures.n; i++) { texture *t = (texture *)g_textures.v[i]; if (!t) continue; free(t->ranvec); free(t->perm); free(t->pixels); free(t); }
     g_textures.n = 0;
 }
 
@@ -108,6 +135,12 @@ material *material_light_new(texture *t) { material *m = mat_alloc(RT_MAT_LIGHT)
 material *material_light_new_from_color(color c) { return material_light_new(texture_solid_color_init(c)); }
 material *material_isotropic_new(texture *t) { material *m = mat_alloc(RT_MAT_ISOTROPIC); m->tex = t; return m; }
 material *material_isotropic_new_from_color(color c) { return material_isotropic_new(texture_solid_color_init(c)); }
+/* material.c:26-33: one material (its texture stays with the texture registry); the registry slot is cleared */
+void material_free(material *m) {
+    if (!m) return;
+    if (m->id >= 0 && m->id < g_materials.n && g_materials.v[m->id] == m) g_materials.v[m->id] = NULL;
+    free(m);
+}
 void materials_free_all(void) { for (int i = 0; i < g_materials.n; i++) free(g_materials.v[i]); g_materials.n = 0; }
 
 /* ---- lists ---------------------------------------------------------------------------------- */
@@ -286,4 +319,35 @@ void camera_fields(const camera *c, double out[24]) {
     const vec3 *v[7] = {&c->origin, &c->lower_left_corner, &c->horizontal, &c->vertical, &c->u, &c->v, &c->w};
     for (int i = 0; i < 7; i++) { out[3 * i] = v[i]->x; out[3 * i + 1] = v[i]->y; out[3 * i + 2] = v[i]->z; }
     out[21] = c->lens_radius; out[22] = c->time0; out[23] = c->time1;
+}
+
+/* camera.c:46-53, on the host, for code that wants single rays (tests, rtc_ray_colors callers): the lens sample is the
+ * rejection loop of vec3.c:87-93 and the ray time one more rand() draw, both consumed even for a pinhole camera with a
+ * closed shutter (F13) -- the reference's rand() stream stays in step.  The renderer does not call this: its primary rays
+ * are generated on the device from Philox. */
+ray camera_get_ray(camera *c, double s, double t) {
+    vec3 p;
+    for (;;) {   /* x first: the reference's initialiser list draws left to right */
+        p.x = random_double_scaled(-1, 1); p.y = random_double_scaled(-1, 1); p.z = 0;
+        if ((p.x * p.x) + (p.y * p.y) + (p.z * p.z) < 1) break;
+    }
+    vec3 rd = mul3(p, c->lens_radius);
+    vec3 offset = add3(mul3(c->u, rd.x), mul3(c->v, rd.y));
+    vec3 dir = sub3(add3(add3(c->lower_left_corner, mul3(c->horizontal, s)), mul3(c->vertical, t)), c->origin);
+    ray r;
+    r.dir = sub3(dir, offset); r.orig = add3(c->origin, offset); r.time = random_double_scaled(c->time0, c->time1);
+    return r;
+}
+
+/* ray.c:35-47 on the host: average, gamma 2, clamp to [0, 0.999], x256 -> three bytes at `index`.  A NaN component writes
+ * 0 (the reference casts it to unsigned char: undefined, F16).  rtc_tonemap_u8 is the same arithmetic for a whole image. */
+void write_color(unsigned char *pixels, color *pixel_color, int samples_per_pixel, int index) {
+    const double scale = 1.0 / (double)samples_per_pixel;
+    const double c[3] = {pixel_color->x, pixel_color->y, pixel_color->z};
+    for (int k = 0; k < 3; k++) {
+        double v = sqrt(scale * c[k]);
+        v = (v < 0.0) ? 0.0 : ((v > 0.999) ? 0.999 : v);
+        if (!(v == v)) v = 0.0;
+        pixels[index + k] = (unsigned char)(256 * v);
+    }
 }

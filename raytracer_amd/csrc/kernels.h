@@ -45,7 +45,8 @@ struct WfBuffers {
     unsigned char *key;               // regrouping key of the hit written by extend: material type * 4 + texture type, 31 = miss
     int *active[2];                   // slot lists (ping-pong across compactions); -1 = hole
     unsigned *counters;               // 16 words: [0] live slots, [1] compaction cursor
-    unsigned long long *stats;        // wf_stats_bytes(): [0] rays, [1] extend waves; 16 striped partial counters behind
+    unsigned long long *stats;        // wf_stats_bytes(): 16 striped partial counters (rays, extend waves) behind one unused line; scene-wide like the pool
+    unsigned long long *stats_out;    // [0] rays, [1] extend waves of the calling stream: k_wf_finish folds the stripes into them
     int n_slots, slots_per_layer, layers;
     int quad;                         // slot <-> (pixel, layer) mapping of kernels_wf.hip slot_pixel
 };
@@ -58,3 +59,15 @@ hipError_t launch_wf_bounce(const SceneT<float> &sc, const CameraT<float> &cam, 
 // list `cur` -> list `cur ^ 1` without holes
 hipError_t launch_wf_compact(const WfBuffers &b, int cur, unsigned n_list, hipStream_t stream);
 hipError_t launch_wf_finish(const RenderParams &p, const WfBuffers &b, float4 *accum, hipStream_t stream);
+
+// ---- single rays and known-answer probes (kernels_probe.hip, kernels_small.hip) --------------------------------------
+// rgb_sum[3 i ..] += the estimator of ray i summed over samples [p.s_begin, p.s_end), `chunks` lanes per ray
+hipError_t launch_ray_colors(const SceneT<float> &sc, const RenderParams &p, const float *rays7, unsigned n, unsigned chunks, double *rgb_sum,
+                             unsigned long long *ray_counter, hipStream_t stream);
+// rtc_kat (include/rtc.h): `what` selects the device function; doubles in, doubles out
+enum { RTC_KAT_PHILOX = 0, RTC_KAT_LIGHT_PDF = 1, RTC_KAT_LIGHT_PDF_SMALL = 2, RTC_KAT_COSINE_PDF = 3, RTC_KAT_SCHLICK = 4, RTC_KAT_REFRACT = 5,
+       RTC_KAT_LIGHT_SAMPLE = 6, RTC_KAT_LIGHT_SAMPLE_SMALL = 7, RTC_KAT_DIELECTRIC = 8, RTC_KAT_DIELECTRIC_SMALL = 9, RTC_KAT_COUNT = 10 };
+__host__ __device__ inline int rtc_kat_in_stride(int what) { const int s[RTC_KAT_COUNT] = {5, 6, 6, 6, 2, 7, 6, 6, 9, 9}; return what >= 0 && what < RTC_KAT_COUNT ? s[what] : 0; }
+__host__ __device__ inline int rtc_kat_out_stride(int what) { const int s[RTC_KAT_COUNT] = {4, 1, 1, 1, 1, 3, 3, 3, 3, 3}; return what >= 0 && what < RTC_KAT_COUNT ? s[what] : 0; }
+hipError_t launch_kat(const SceneT<float> &sc, int what, const double *in, unsigned n, double *out, hipStream_t stream);
+hipError_t launch_small_kat(const SceneT<float> &sc, int what, const double *in, unsigned n, double *out, hipStream_t stream);

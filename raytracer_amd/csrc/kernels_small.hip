@@ -44,7 +44,9 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 //   max(lo - p, p - hi, tmin - t, t - tbest) <= 0
 // so no lane masks are combined on the (single, shared) scalar unit; packed FP32 math does both in-plane axes at once.
 // tbest starts at a large FINITE value: a t of +inf (dn == 0) then violates t - tbest, NaNs fail the compare.
-RT_DEV void small_pair(const SmallPair &P, float on, float in, v2f oab, v2f dab, float tmin, SmallHit &h) {
+// A ray cannot hit the plane it leaves again: the leaf it starts on (src) is excluded -- in FP32 the start point is off the
+// plane by up to |k| 2^-24 (3e-5 at k = 555) and a grazing ray (|d_n| < 0.03) would meet it again at t >= tmin.
+RT_DEV void small_pair(const SmallPair &P, float on, float in, v2f oab, v2f dab, float tmin, int src, SmallHit &h) {
     const v2f k = {P.f[0], P.f[1]};
     const int id0 = __float_as_int(P.f[10]), id1 = __float_as_int(P.f[11]);
     const v2f t = (k - on) * in;
@@ -53,7 +55,7 @@ RT_DEV void small_pair(const SmallPair &P, float on, float in, v2f oab, v2f dab,
         const v2f lo = {P.f[2], P.f[3]}, hi = {P.f[4], P.f[5]};
         const v2f vl = lo - p, vh = p - hi;
         const float viol = fmaxf(fmaxf(fmaxf(vl.x, vl.y), fmaxf(vh.x, vh.y)), fmaxf(tmin - t.x, t.x - h.t));
-        const bool hit = viol <= 0.0f;
+        const bool hit = (viol <= 0.0f) & (id0 != src);
         h.t = hit ? t.x : h.t; h.leaf = hit ? id0 : h.leaf;
     }
     if (id1 >= 0) {   // wave-uniform (a scalar compare): the run had an odd number of rects and this is its padding
@@ -61,18 +63,19 @@ RT_DEV void small_pair(const SmallPair &P, float on, float in, v2f oab, v2f dab,
         const v2f lo = {P.f[6], P.f[7]}, hi = {P.f[8], P.f[9]};
         const v2f vl = lo - p, vh = p - hi;
         const float viol = fmaxf(fmaxf(fmaxf(vl.x, vl.y), fmaxf(vh.x, vh.y)), fmaxf(tmin - t.y, t.y - h.t));
-        const bool hit = viol <= 0.0f;
+        const bool hit = (viol <= 0.0f) & (id1 != src);
         h.t = hit ? t.y : h.t; h.leaf = hit ? id1 : h.leaf;
     }
 }
-RT_DEV void small_run(const SmallScene &ss, int first, int count, float on, float in, float oa, float da, float ob, float db, float tmin, SmallHit &h) {
+RT_DEV void small_run(const SmallScene &ss, int first, int count, float on, float in, float oa, float da, float ob, float db, float tmin, int src, SmallHit &h) {
     const v2f oab = {oa, ob}, dab = {da, db};
-    for (int p = first; p < first + count; ++p) small_pair(ss.pairs[p], on, in, oab, dab, tmin, h);   // wave-uniform: one s_load_dwordx16
+    for (int p = first; p < first + count; ++p) small_pair(ss.pairs[p], on, in, oab, dab, tmin, src, h);   // wave-uniform: one s_load_dwordx16
 }
 // box_hit (hittable.c:521-523 = the list scan over the sides) as one slab test, also for a box with openings: the surface is entered at the largest
 // near-plane parameter and left at the smallest far-plane parameter; a ray that starts inside (or on) the box hits the
 // exit face.  The face gives the leaf id, so shading sees the same record as after six rect tests.
-RT_DEV void small_box(const SmallBox &B, f3 o, f3 inv, float tmin, SmallHit &h) {
+// A ray that starts on a face (src) cannot hit that face again (rt_core.hpp box_leaf_t): not as the entry, not as the exit.
+RT_DEV void small_box(const SmallBox &B, f3 o, f3 inv, float tmin, int src, SmallHit &h) {
     const float x0 = (B.lo[0] - o.x) * inv.x, x1 = (B.hi[0] - o.x) * inv.x;
     const float y0 = (B.lo[1] - o.y) * inv.y, y1 = (B.hi[1] - o.y) * inv.y;
     const float z0 = (B.lo[2] - o.z) * inv.z, z1 = (B.hi[2] - o.z) * inv.z;
@@ -86,29 +89,29 @@ RT_DEV void small_box(const SmallBox &B, f3 o, f3 inv, float tmin, SmallHit &h) 
     const uint32_t id_out = ((inv_out > 0.0f ? B.ids_hi : B.ids_lo) >> (8 * ax_out)) & 0xffu;
     // the entry point counts when it is in range and that face exists; otherwise (ray starts inside, or enters through an
     // opening) the exit point
-    const bool enter = (t_in >= tmin) & (id_in != 0xffu);
+    const bool enter = (t_in >= tmin) & (id_in != 0xffu) & (id_in != (uint32_t)src);
     const float t = enter ? t_in : t_out;
     const uint32_t id = enter ? id_in : id_out;
-    const bool hit = (t_in <= t_out) & (t >= tmin) & (t <= h.t) & (id != 0xffu);
+    const bool hit = (t_in <= t_out) & (t >= tmin) & (t <= h.t) & (id != 0xffu) & (id != (uint32_t)src);
     h.t = hit ? t : h.t; h.leaf = hit ? (int)id : h.leaf;
 }
 // the records of one object space against the ray in that space
-RT_DEV void small_group_hit(const SmallScene &ss, const SmallGroup &g, f3 o, f3 d, f3 inv, float tmin, SmallHit &h) {
-    if (g.box >= 0) small_box(ss.boxes[g.box], o, inv, tmin, h);
+RT_DEV void small_group_hit(const SmallScene &ss, const SmallGroup &g, f3 o, f3 d, f3 inv, float tmin, int src, SmallHit &h) {
+    if (g.box >= 0) small_box(ss.boxes[g.box], o, inv, tmin, src, h);
     int first = g.first;
-    small_run(ss, first, g.n_xy, o.z, inv.z, o.x, d.x, o.y, d.y, tmin, h); first += g.n_xy;
-    small_run(ss, first, g.n_xz, o.y, inv.y, o.x, d.x, o.z, d.z, tmin, h); first += g.n_xz;
-    small_run(ss, first, g.n_yz, o.x, inv.x, o.y, d.y, o.z, d.z, tmin, h);
+    small_run(ss, first, g.n_xy, o.z, inv.z, o.x, d.x, o.y, d.y, tmin, src, h); first += g.n_xy;
+    small_run(ss, first, g.n_xz, o.y, inv.y, o.x, d.x, o.z, d.z, tmin, src, h); first += g.n_xz;
+    small_run(ss, first, g.n_yz, o.x, inv.x, o.y, d.y, o.z, d.z, tmin, src, h);
 }
-// hittable_list_hit (hittable_list.c:125-143) over the packed leaves.  `src` = leaf the ray starts on: only spheres need
-// it (rt_core.hpp sphere_leave_t); a rect left behind is rejected by tmin like in the reference.
+// hittable_list_hit (hittable_list.c:125-143) over the packed leaves.  `src` = leaf the ray starts on: a sphere left behind
+// has the roots {0, 2 tc} (rt_core.hpp sphere_leave_t), a rect or box face left behind is not tested again.
 RT_DEV SmallHit small_closest_hit(const SmallScene &ss, f3 ow, f3 dw, float tmin, int src) {
     SmallHit h; h.t = 3.0e38f; h.leaf = -1;
     const f3 invw = rcp3(dw);
     // The world-space group (xform 0 sorts first, flatten.cpp build_small_pack) runs on the world ray as it is; written as
     // one loop with `o = ow; if (xform) o = ...` the compiler copies nine registers per group to have something to overwrite.
     int gi = 0;
-    if (ss.n_groups > 0 && ss.groups[0].xform == 0) { small_group_hit(ss, ss.groups[0], ow, dw, invw, tmin, h); gi = 1; }
+    if (ss.n_groups > 0 && ss.groups[0].xform == 0) { small_group_hit(ss, ss.groups[0], ow, dw, invw, tmin, src, h); gi = 1; }
     for (; gi < ss.n_groups; ++gi) {
         const SmallGroup g = ss.groups[gi];                      // wave-uniform
         const SmallXform x = ss.xforms[g.xform];
@@ -118,7 +121,7 @@ RT_DEV SmallHit small_closest_hit(const SmallScene &ss, f3 ow, f3 dw, float tmin
             d = f3mk(x.m[0] * dw.x + x.m[2] * dw.z, dw.y, x.m[6] * dw.x + x.m[8] * dw.z);
             inv = f3mk(__builtin_amdgcn_rcpf(d.x), invw.y, __builtin_amdgcn_rcpf(d.z));
         } else { o = xform_point(x, ow); d = xform_dir(x, dw); inv = rcp3(d); }
-        small_group_hit(ss, g, o, d, inv, tmin, h);
+        small_group_hit(ss, g, o, d, inv, tmin, src, h);
     }
     if (ss.n_spheres > 0) {                                      // world space, closest-approach form (rt_core.hpp sphere_t<float>)
         for (int s = 0; s < ss.n_spheres; ++s) {                 // |dw| = 1 (every ray of this kernel): the quadratic's a is 1
@@ -373,8 +376,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) k
                     }
 #endif
                     nd = nd * __builtin_amdgcn_rsqf(len2(nd));              // unit from here on: the pdfs and the next bounce's tests drop |v|
-                    const float cosn = dot(n, nd);
-                    const float pdf_cos = cosn > 0.0f ? cosn * RT_INV_PI : 0.0f;      // pdf.c:100-103 == material.c:205-208
+                    const float pdf_cos = lambert_pdf(n, nd);                         // pdf.c:100-103 == material.c:205-208
                     const float pdf_light = sc.n_lights > 0 ? small_light_pdf_sum(sc, p, nd) : 0.0f;   // x 1 / n_lights below
 #if RT_EXP == 5   // cost probe: the light-list pdf twice
                     const float pdf_light2 = sc.n_lights > 0 ? small_light_pdf_sum(sc, p + f3mk(1e-9f * (float)iters, 0, 0), nd) : 0.0f;
@@ -436,7 +438,33 @@ __global__ void __launch_bounds__(1024) k_tile_order(const int *__restrict__ cos
     for (int t = threadIdx.x; t < n; t += 1024) perm[atomicAdd(&bin_start[1023 - min(max(cost[t], 0), 1023)], 1u)] = t;
 }
 
+// Known-answer probe of this file's own shading functions (they differ from rt_shade.hpp's: unit directions, folded hit
+// tests, basis-free samplers), on supplied inputs; kernels_probe.hip has the general ones.
+__global__ void __launch_bounds__(256) k_small_kat(SceneT<float> sc, int what, const double *__restrict__ in, unsigned n, double *__restrict__ out) {
+    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int si = rtc_kat_in_stride(what), so = rtc_kat_out_stride(what);
+    const double *a = in + (size_t)si * i;
+    double *o = out + (size_t)so * i;
+    auto v3at = [&](int k) { return f3mk((float)a[k], (float)a[k + 1], (float)a[k + 2]); };
+    if (what == RTC_KAT_LIGHT_PDF_SMALL) {            // the list pdf as the bounce loop computes it: sum over the lights for a UNIT direction, / n
+        o[0] = sc.n_lights > 0 ? small_light_pdf_sum(sc, v3at(0), normalize(v3at(3))) / (float)sc.n_lights : 0.0f;
+    } else if (what == RTC_KAT_LIGHT_SAMPLE_SMALL) {
+        const f3 d = small_light_sample(sc, (int)a[3], v3at(0), (float)a[4], (float)a[5]);
+        o[0] = d.x; o[1] = d.y; o[2] = d.z;
+    } else if (what == RTC_KAT_DIELECTRIC_SMALL) {
+        const f3 d = small_dielectric_dir((float)a[7], normalize(v3at(0)), v3at(3), a[6] != 0.0, (float)a[8]);
+        o[0] = d.x; o[1] = d.y; o[2] = d.z;
+    } else for (int k = 0; k < so; ++k) o[k] = 0.0;
+}
+
 }  // namespace
+
+hipError_t launch_small_kat(const SceneT<float> &sc, int what, const double *in, unsigned n, double *out, hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_small_kat, dim3((n + 255) / 256), dim3(256), 0, stream, sc, what, in, n, out);
+    return hipGetLastError();
+}
 
 template <bool PROBE>
 static void launch_small(const SmallScene &ss, const SceneT<float> &sc, const CameraT<float> &cam, const RenderParams &p, float4 *accum,

@@ -275,12 +275,13 @@ __global__ void __launch_bounds__(1024) k_wf_compact(WfBuffers B, int cur, unsig
     if (live) B.active[cur ^ 1][block_base + before + (unsigned)__builtin_popcountll(mask & ((1ull << lane) - 1ull))] = slot;
 }
 
-__global__ void __launch_bounds__(256) k_wf_finish(RenderParams P, WfBuffers B, float4 *__restrict__ accum, unsigned long long *__restrict__ stats) {
+__global__ void __launch_bounds__(256) k_wf_finish(RenderParams P, WfBuffers B, float4 *__restrict__ accum, const unsigned long long *__restrict__ stats,
+                                                   unsigned long long *__restrict__ stats_out) {
     const int q = blockIdx.x * blockDim.x + threadIdx.x;            // slot of layer 0
-    if (q == 0) {                                                    // fold the striped statistics
+    if (q == 0) {                                                    // fold the striped statistics into the calling stream's counters
         unsigned long long rays = 0, waves = 0;
         for (int k = 0; k < kWfStripes; ++k) { rays += stats[8 * (1 + k)]; waves += stats[8 * (1 + kWfStripes + k)]; }
-        stats[0] += rays; stats[1] += waves;
+        stats_out[0] += rays; stats_out[1] += waves;
     }
     if (q >= B.slots_per_layer) return;
     const int tile = q >> 6, x = q & 7, y = (q >> 3) & 7;
@@ -326,6 +327,6 @@ hipError_t launch_wf_compact(const WfBuffers &b, int cur, unsigned n_list, hipSt
     return hipGetLastError();
 }
 hipError_t launch_wf_finish(const RenderParams &p, const WfBuffers &b, float4 *accum, hipStream_t stream) {
-    hipLaunchKernelGGL(k_wf_finish, dim3((unsigned)((b.slots_per_layer + 255) / 256)), dim3(256), 0, stream, p, b, accum, b.stats);
+    hipLaunchKernelGGL(k_wf_finish, dim3((unsigned)((b.slots_per_layer + 255) / 256)), dim3(256), 0, stream, p, b, accum, b.stats, b.stats_out);
     return hipGetLastError();
 }

@@ -105,6 +105,9 @@ struct StreamState {
     DevBuf tile_scratch; size_t tile_scratch_cap = 0;   // cost + order of the 8x8 tiles
     DevBuf small_partial; size_t small_partial_cap = 0; // per-chunk partial sums (float4 per pixel and chunk)
     std::vector<unsigned char> order_key;               // what the tile order in tile_scratch was probed for (camera, size, depth, integrator)
+    // [0] rays, [1] wave bounce-iterations of the last render on THIS stream.  One buffer per stream: renders of one scene on
+    // two streams may overlap, and with a buffer per scene they added into -- or wiped -- each other's counts.
+    DevBuf stats;
 };
 
 }  // namespace
@@ -114,7 +117,7 @@ struct rtc_scene {
     int device = -1;
     DeviceTables<float> f32;
     DeviceTables<double> f64;
-    DevBuf ray_counter;
+    DevBuf ray_counter;                        // wavefront only: striped statistics + queue counters, ordered across streams by wf_done like the pool
     DevBuf wf_pool; size_t wf_slots_cap = 0;   // wavefront path-slot state, grown on demand
     hipEvent_t wf_done = nullptr;              // end of the last wavefront render's final accumulate: the pool is shared by all streams
     DevBuf small_pairs, small_groups, small_spheres, small_shade, small_xforms, small_boxes;
@@ -344,7 +347,7 @@ static int check_settings(const rtc_settings *st) {
 // Wavefront driver (kernels_wf.hip): init, then extend + shade per bounce until no slot is live, then the accumulate.
 // The live count is read back every few bounces, so this path returns only when the work has been ENQUEUED AND RUN up to
 // the final accumulate (which is left in flight on `stream`).
-static int render_wavefront(rtc_scene *s, const CameraT<float> &camf, const RenderParams &p, float4 *accum, hipStream_t stream) {
+static int render_wavefront(rtc_scene *s, const CameraT<float> &camf, const RenderParams &p, float4 *accum, unsigned long long *stats_out, hipStream_t stream) {
     const int spp = p.s_end - p.s_begin;
     if (spp <= 0) return RTC_OK;
     const long long per_layer = (long long)p.n_tiles * 64;
@@ -383,7 +386,7 @@ static int render_wavefront(rtc_scene *s, const CameraT<float> &camf, const Rend
     b.active[0] = (int *)base; base += n * sizeof(int);
     b.active[1] = (int *)base; base += n * sizeof(int);
     b.key = (unsigned char *)base; base += n;
-    b.stats = (unsigned long long *)s->ray_counter.p;
+    b.stats = (unsigned long long *)s->ray_counter.p; b.stats_out = stats_out;
     b.counters = (unsigned *)((char *)s->ray_counter.p + wf_stats_bytes());
     b.n_slots = (int)n_slots; b.slots_per_layer = (int)per_layer; b.layers = (int)layers;
     b.quad = layers % 4 == 0;
@@ -431,7 +434,9 @@ int rtc_render_device(const rtc_scene *scene_c, const camera *cam, const rtc_set
     p.tiles_x = (st->width + 7) / 8; p.tiles_y = (st->height + 7) / 8; p.n_tiles = p.tiles_x * p.tiles_y;
     const CameraT<float> camf = camera_tables<float>(cam);
     p.use_time = camf.time0 != camf.time1;
-    HIP_TRY(hipMemsetAsync(s->ray_counter.p, 0, 4 * sizeof(unsigned long long), stream));
+    if (!ss.stats.p) { const unsigned long long zero[4] = {0, 0, 0, 0}; HIP_TRY(ss.stats.upload(zero, sizeof zero)); }
+    unsigned long long *const stats = (unsigned long long *)ss.stats.p;
+    HIP_TRY(hipMemsetAsync(stats, 0, 4 * sizeof(unsigned long long), stream));
     HIP_TRY(hipEventRecord(ss.ev0, stream));
     const bool small = st->kernel == 2 || (st->kernel == 0 && s->small.n_leaves > 0);
     if (small && s->small.n_leaves <= 0)
@@ -470,12 +475,12 @@ int rtc_render_device(const rtc_scene *scene_c, const camera *cam, const rtc_set
             else { ss.small_partial.p = nullptr; log2_chunks = 0; }   // no scratch: one wave per tile
         }
         int ordered = reuse_order ? 1 : 0;
-        HIP_TRY(launch_pathtrace_small(s->small, s->f32.view, camf, p, (float4 *)accum_dev, (unsigned long long *)s->ray_counter.p, (int *)ss.tile_scratch.p,
+        HIP_TRY(launch_pathtrace_small(s->small, s->f32.view, camf, p, (float4 *)accum_dev, stats, (int *)ss.tile_scratch.p,
                                        &ordered, log2_chunks ? (float4 *)ss.small_partial.p : nullptr, log2_chunks, stream));
         if (ordered) ss.order_key = key; else ss.order_key.clear();
     }
-    else if (wavefront) { rc = render_wavefront(s, camf, p, (float4 *)accum_dev, stream); if (rc) return rc; }
-    else HIP_TRY(launch_pathtrace_mega(s->f32.view, camf, p, (float4 *)accum_dev, (unsigned long long *)s->ray_counter.p, stream));
+    else if (wavefront) { rc = render_wavefront(s, camf, p, (float4 *)accum_dev, stats, stream); if (rc) return rc; }
+    else HIP_TRY(launch_pathtrace_mega(s->f32.view, camf, p, (float4 *)accum_dev, stats, stream));
     ss.kernel = small ? 2 : (wavefront ? 3 : 1);
     HIP_TRY(hipEventRecord(ss.ev1, stream));
     ss.samples = (uint64_t)st->width * st->height * (uint64_t)(st->sample_end - st->sample_begin);
@@ -493,7 +498,7 @@ int rtc_render_stats(const rtc_scene *scene_c, void *stream_v, rtc_stats *out) {
     HIP_TRY(hipEventSynchronize(ss.ev1));
     float ms = 0; HIP_TRY(hipEventElapsedTime(&ms, ss.ev0, ss.ev1));
     unsigned long long cnt[4] = {0, 0, 0, 0};
-    HIP_TRY(hipMemcpy(cnt, s->ray_counter.p, sizeof cnt, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(cnt, ss.stats.p, sizeof cnt, hipMemcpyDeviceToHost));
     const unsigned long long rays = cnt[0];
     std::memset(out, 0, sizeof *out);
     out->samples = ss.samples; out->rays = rays; out->kernel_ms = ms; out->total_ms = ss.total_ms > 0 ? ss.total_ms : ms;
@@ -513,8 +518,89 @@ int rtc_render(const rtc_scene *scene, const camera *cam, const rtc_settings *st
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(accum_host, acc.p, bytes, hipMemcpyDeviceToHost));
     rtc_scene *s = const_cast<rtc_scene *>(scene);
-    s->streams[nullptr].total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    const double total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    { std::lock_guard<std::mutex> lk(s->mu); s->streams[nullptr].total_ms = total_ms; }
     return RTC_OK;
+}
+
+// ray_color (ray.c:50-84 and its 02 / 01 forms) for rays the caller supplies: the general bounce loop of kernels_probe.hip.
+int rtc_ray_colors(const rtc_scene *scene_c, const double *rays7, size_t n, const rtc_settings *st, double *rgb_sum) {
+    rtc_scene *s = const_cast<rtc_scene *>(scene_c);
+    if (!s || (!rays7 && n) || (!rgb_sum && n) || !st) return fail(RTC_ERR_ARG, "rtc_ray_colors: null argument");
+    if (int rc_dev = check_device(s)) return rc_dev;
+    if (st->sample_end < st->sample_begin || st->sample_begin < 0) return fail(RTC_ERR_ARG, "rtc_ray_colors: bad sample range");
+    if (st->max_depth < 0 || st->max_depth > 4096) return fail(RTC_ERR_ARG, "rtc_ray_colors: bad max_depth");
+    if (st->integrator < 0 || st->integrator > 2) return fail(RTC_ERR_ARG, "rtc_ray_colors: integrator must be 0, 1 or 2");
+    if (n > (1u << 24)) return fail(RTC_ERR_ARG, "rtc_ray_colors: at most 2^24 rays per call");
+    if (n == 0 || st->sample_end == st->sample_begin) return RTC_OK;
+    std::lock_guard<std::mutex> lk(s->mu);
+    RenderParams p; std::memset(&p, 0, sizeof p);
+    p.s_begin = st->sample_begin; p.s_end = st->sample_end; p.max_depth = st->max_depth; p.integrator = st->integrator;
+    p.seed_lo = (uint32_t)st->seed; p.seed_hi = (uint32_t)(st->seed >> 32);
+    p.light_weight = s->flat.lights.empty() ? 0.0f : (float)st->mixture_light_weight;
+    p.light_weight_each = s->flat.lights.empty() ? 0.0f : p.light_weight / (float)s->flat.lights.size(); p.cosine_weight = 1.0f - p.light_weight;
+    std::vector<float> rf(n * 7);
+    for (size_t i = 0; i < n * 7; i++) rf[i] = (float)rays7[i];
+    DevBuf d_rays, d_sum, d_cnt;
+    HIP_TRY(d_rays.upload(rf.data(), rf.size() * sizeof(float)));
+    HIP_TRY(d_sum.upload(rgb_sum, n * 3 * sizeof(double)));            // the call ADDS, like rtc_render
+    const unsigned long long zero = 0; HIP_TRY(d_cnt.upload(&zero, sizeof zero));
+    // enough lanes to fill the chip when few rays carry many samples, never more lanes than samples
+    const long long spp = st->sample_end - st->sample_begin;
+    long long chunks = (long long)((1u << 20) / n); if (chunks < 1) chunks = 1; if (chunks > spp) chunks = spp; if (chunks > 4096) chunks = 4096;
+    HIP_TRY(launch_ray_colors(s->f32.view, p, (const float *)d_rays.p, (unsigned)n, (unsigned)chunks, (double *)d_sum.p, (unsigned long long *)d_cnt.p, nullptr));
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(rgb_sum, d_sum.p, n * 3 * sizeof(double), hipMemcpyDeviceToHost));
+    return RTC_OK;
+}
+
+// Known-answer probe of the device functions the production kernels call (tests only).
+int rtc_kat(const rtc_scene *scene_c, int what, const double *in, size_t n, double *out) {
+    rtc_scene *s = const_cast<rtc_scene *>(scene_c);
+    if (!s || (!in && n) || (!out && n)) return fail(RTC_ERR_ARG, "rtc_kat: null argument");
+    if (what < 0 || what >= RTC_KAT_COUNT) return fail(RTC_ERR_ARG, "rtc_kat: unknown function");
+    if (int rc_dev = check_device(s)) return rc_dev;
+    if (n == 0) return RTC_OK;
+    if (n > (1u << 24)) return fail(RTC_ERR_ARG, "rtc_kat: at most 2^24 inputs per call");
+    const bool small = what == RTC_KAT_LIGHT_PDF_SMALL || what == RTC_KAT_LIGHT_SAMPLE_SMALL || what == RTC_KAT_DIELECTRIC_SMALL;
+    std::lock_guard<std::mutex> lk(s->mu);
+    DevBuf d_in, d_out;
+    HIP_TRY(d_in.upload(in, n * (size_t)rtc_kat_in_stride(what) * sizeof(double)));
+    HIP_TRY(hipMalloc(&d_out.p, n * (size_t)rtc_kat_out_stride(what) * sizeof(double)));
+    if (small) HIP_TRY(launch_small_kat(s->f32.view, what, (const double *)d_in.p, (unsigned)n, (double *)d_out.p, nullptr));
+    else HIP_TRY(launch_kat(s->f32.view, what, (const double *)d_in.p, (unsigned)n, (double *)d_out.p, nullptr));
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out, d_out.p, n * (size_t)rtc_kat_out_stride(what) * sizeof(double), hipMemcpyDeviceToHost));
+    return RTC_OK;
+}
+
+// ray.h:39 -- color ray_color(ray*, color* background, hittable_list* world, hittable_list* lights, int depth): one sample of
+// the 03 estimator for one ray, on the GPU.  The device tables of (world, lights, background) are kept between calls.
+color ray_color(ray *r, color *background, hittable_list *world, hittable_list *lights, int recursion_depth) {
+    static std::mutex mu;
+    static rtc_scene *cached = nullptr;
+    static const hittable_list *c_world = nullptr, *c_lights = nullptr;
+    static int c_nw = -1, c_nl = -1; static color c_bg = {0, 0, 0};
+    static unsigned long long calls = 0;
+    const color black = {0, 0, 0};
+    if (!r || !world) return black;
+    std::lock_guard<std::mutex> lk(mu);
+    const color bg = background ? *background : black;
+    const int nw = hittable_list_index(world), nl = lights ? hittable_list_index(lights) : 0;
+    if (!cached || c_world != world || c_lights != lights || c_nw != nw || c_nl != nl || c_bg.x != bg.x || c_bg.y != bg.y || c_bg.z != bg.z) {
+        if (cached) { rtc_scene_free(cached); cached = nullptr; }
+        cached = rtc_scene_build(world, lights, &bg, 0.0, 1.0);
+        if (!cached) { std::printf("!! ray_color: %s\n", rtc_last_error()); return black; }
+        c_world = world; c_lights = lights; c_nw = nw; c_nl = nl; c_bg = bg;
+    }
+    rtc_settings st; std::memset(&st, 0, sizeof st);
+    st.width = st.height = 2; st.max_depth = recursion_depth; st.integrator = 0; st.mixture_light_weight = 0.1;   // ray.c:72
+    st.sample_begin = (int)(calls & 0xffffff); st.sample_end = st.sample_begin + 1; st.seed = calls >> 24; ++calls;
+    const double ray7[7] = {r->orig.x, r->orig.y, r->orig.z, r->dir.x, r->dir.y, r->dir.z, r->time};
+    double rgb[3] = {0, 0, 0};
+    if (rtc_ray_colors(cached, ray7, 1, &st, rgb) != RTC_OK) { std::printf("!! ray_color: %s\n", rtc_last_error()); return black; }
+    const color out = {rgb[0], rgb[1], rgb[2]};
+    return out;
 }
 
 int rtc_tonemap_u8_device(const float *accum_dev, int width, int height, unsigned char *rgb_dev, void *stream) {

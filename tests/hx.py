@@ -4,6 +4,8 @@ The same flat ``hx_*`` ABI is exported by three libraries:
   * ``oracle/_build/liboracle.so``  the CPU restatement (oracle/cpu_ref.c)
   * ``oracle/_ref/libref03.so``     the reference's 03_FullTracer compiled in place
   * ``oracle/_ref/libref02.so``     the reference's 02_AdvancedTracer compiled in place
+``oracle/_ref/libref01.so`` (the reference's 01_BasicTracer, one header-only translation unit with an API of its own)
+exports the ``hx01_*`` probes of oracle/harness01.c instead: class ``Ref01``.
 Only tests/, smoke() and bench.py's cpu_baseline leg import this module.
 """
 import ctypes as C
@@ -15,6 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_SO = os.path.join(ROOT, "oracle", "_build", "liboracle.so")
 REF03_SO = os.path.join(ROOT, "oracle", "_ref", "libref03.so")
 REF02_SO = os.path.join(ROOT, "oracle", "_ref", "libref02.so")
+REF01_SO = os.path.join(ROOT, "oracle", "_ref", "libref01.so")
 EARTHMAP = os.path.join(ROOT, "tests", "golden", "earthmap_512.ppm")   # image asset of the earth scenes (make_earth_fixture.py)
 
 SCENE = dict(simple=0, cornell=1, final=2, book1=3, cornell02=4, cornell_smoke=5, two_spheres=6,
@@ -216,6 +219,17 @@ class Harness:
         self.lib.hx_unit_write_color(C.c_int(n), p, C.c_int(spp), out.ctypes.data_as(_bp))
         return out
 
+    def render_ppm01(self, path, w, h, spp, depth, seed=None):
+        """Oracle only, stage 1: the serial loop of 01 main.c:168-191 into an ASCII PPM; seed None continues the rand() stream."""
+        assert self.is_oracle
+        return self.lib.hx_render_ppm01(path.encode(), C.c_int(w), C.c_int(h), C.c_int(spp), C.c_int(depth),
+                                        C.c_int(0 if seed is None else 1), C.c_uint(seed or 0))
+
+    def write_colors_ppm(self, path, rgb3, spp):
+        assert self.is_oracle
+        rgb3, p = _d(rgb3)
+        return self.lib.hx_write_colors_ppm(path.encode(), C.c_int(rgb3.size // 3), p, C.c_int(spp))
+
     # -- oracle only ---------------------------------------------------------------------------
     def oracle_render(self, w, h, s_begin, s_end, depth=0, rng="philox", seed=0, threads=0, iterative=True,
                       scrub_nan=True):
@@ -257,3 +271,75 @@ def ref03():
 
 def ref02():
     return Harness(REF02_SO)
+
+
+class Ref01:
+    """The compiled 01_BasicTracer (oracle/harness01.c).  Rays are 6 doubles (no time), records 9 (no u,v)."""
+
+    def __init__(self, path=REF01_SO):
+        if not os.path.exists(path):
+            raise FileNotFoundError(path)
+        self.lib = C.CDLL(path)
+
+    def build(self, seed=1, aspect=0.0):
+        self.n = self.lib.hx01_build(C.c_uint(seed), C.c_double(aspect))
+        return self
+
+    def srand(self, seed):
+        self.lib.hx01_srand(C.c_uint(seed))
+
+    def camera(self):
+        out = np.zeros(22)
+        self.lib.hx01_get_camera(out.ctypes.data_as(_dp))
+        return out
+
+    def spheres(self):
+        out = np.zeros((self.n, 10))
+        self.lib.hx01_dump_spheres(out.ctypes.data_as(_dp), C.c_int(self.n))
+        return out
+
+    def camera_rays(self, uv, seed=1):
+        uv, p = _d(uv)
+        n = uv.size // 2
+        out = np.zeros((n, 6))
+        self.srand(seed)
+        self.lib.hx01_camera_rays(C.c_int(n), p, out.ctypes.data_as(_dp))
+        return out
+
+    def hit_rays(self, rays6, tmin=0.001, tmax=np.inf):
+        rays6, p = _d(rays6)
+        n = rays6.size // 6
+        rec, mat, prim = np.zeros((n, 9)), np.zeros(n, dtype=np.int32), np.zeros(n, dtype=np.int32)
+        self.lib.hx01_hit_rays(C.c_int(n), p, C.c_double(tmin), C.c_double(tmax), rec.ctypes.data_as(_dp), mat.ctypes.data_as(_ip), prim.ctypes.data_as(_ip))
+        return rec, mat, prim
+
+    def ray_colors(self, rays6, depth, seed=1):
+        rays6, p = _d(rays6)
+        n = rays6.size // 6
+        out = np.zeros((n, 3))
+        self.lib.hx01_ray_colors(C.c_uint(seed), C.c_int(n), p, C.c_int(depth), out.ctypes.data_as(_dp))
+        return out
+
+    def scatter(self, mtype, matp, in13, seed=1):
+        matp, pm = _d(matp)
+        in13, pi = _d(in13)
+        n = in13.size // 13
+        out = np.zeros((n, 10))
+        self.lib.hx01_scatter(C.c_int(MAT[mtype]), pm, C.c_uint(seed), C.c_int(n), pi, out.ctypes.data_as(_dp))
+        return out
+
+    def render_ppm(self, path, w, h, spp, depth, seed=None):
+        return self.lib.hx01_render_ppm(path.encode(), C.c_int(w), C.c_int(h), C.c_int(spp), C.c_int(depth),
+                                        C.c_int(0 if seed is None else 1), C.c_uint(seed or 0))
+
+    def write_colors(self, path, rgb3, spp):
+        rgb3, p = _d(rgb3)
+        return self.lib.hx01_write_colors(path.encode(), C.c_int(rgb3.size // 3), p, C.c_int(spp))
+
+    def run_main(self, path):
+        """The reference's real main(): 1920x1080 x 8 spp x depth 8, about two minutes, prints its progress."""
+        return self.lib.hx01_run_main(path.encode())
+
+
+def ref01():
+    return Ref01()

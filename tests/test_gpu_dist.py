@@ -1,0 +1,84 @@
+"""GPU: the multi-rank path end to end on the one GPU a test box has.
+
+Two fresh processes (started with subprocess, so neither inherits an initialised HIP runtime), each rank renders ITS
+shard_samples range of every pixel through rtc_render_device on cuda:0 into its own accumulator, the accumulators are summed
+onto rank 0 with torch.distributed (gloo over host copies here: RCCL needs one GPU per rank; bench.py uses "nccl" on a node),
+rank 0 tonemaps.  The result equals the single-process render of the whole range within float reassociation.
+"""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+WORKER = r"""
+import os, sys
+import numpy as np
+import torch
+import torch.distributed as dist
+sys.path.insert(0, {root!r})
+import raytracer_amd as ra
+from raytracer_amd import dist as rd
+rank, world, port, out = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4]
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
+dist.init_process_group("gloo", rank=rank, world_size=world)
+torch.cuda.set_device(0)
+ra.rtc_init()
+res = {{}}
+for name, W, H, spp in (("cornell", 200, 120, 67), ("book1", 160, 90, 21)):
+    sc, cam, view = ra.build_named_scene(name, aspect=W / H)
+    begin, end = rd.shard_samples(spp, rank, world)
+    acc = rd.new_accum(H, W, "cuda:0")
+    stream = rd.render_into(sc, cam, ra.Settings(W, H, 0, view.max_depth, view.integrator, seed=7, sample_begin=begin, sample_end=end), acc)
+    torch.cuda.synchronize()
+    st = sc.stats(stream)
+    host = acc.cpu()
+    rd.reduce_accum(host, dst=0)                       # the one collective of the path
+    rays = torch.tensor([float(st["rays"])], dtype=torch.float64)
+    dist.reduce(rays, dst=0)
+    if rank == 0:
+        acc.copy_(host)
+        u8 = torch.empty((H, W, 3), dtype=torch.uint8, device="cuda:0")
+        assert ra.lib().rtc_tonemap_u8_device(acc.data_ptr(), W, H, u8.data_ptr(), None) == 0
+        torch.cuda.synchronize()
+        res[name + "_acc"], res[name + "_u8"], res[name + "_rays"] = host.numpy(), u8.cpu().numpy(), rays.numpy()
+    sc.close()
+dist.barrier()
+if rank == 0:
+    np.savez(out, **res)
+dist.destroy_process_group()
+"""
+
+
+def test_two_ranks_on_one_gpu_equal_one_process(gpu, tmp_path):
+    out = str(tmp_path / "ranks.npz")
+    code = WORKER.format(root=ROOT)
+    port = str(29500 + os.getpid() % 400)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, "-c", code, str(r), "2", port, out], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env) for r in range(2)]
+    for p in procs:
+        try:
+            so, se = p.communicate(timeout=240)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        assert p.returncode == 0, se.decode()[-3000:]
+    got = np.load(out)
+    for name, W, H, spp in (("cornell", 200, 120, 67), ("book1", 160, 90, 21)):
+        sc, cam, view = gpu.build_named_scene(name, aspect=W / H)
+        try:
+            acc, st = sc.render(cam, gpu.Settings(W, H, 0, view.max_depth, view.integrator, seed=7, sample_begin=0, sample_end=spp))
+        finally:
+            sc.close()
+        a = got[name + "_acc"]
+        assert (a[..., 3] == spp).all()                                # sample counts add up
+        assert np.allclose(a[..., :3], acc[..., :3], rtol=1e-5, atol=1e-5 * spp)   # float sums reassociated across ranks
+        assert int(got[name + "_rays"][0]) == st["rays"]               # the same paths were traced, split in two
+        d = np.abs(got[name + "_u8"].astype(int) - gpu.tonemap_u8(acc).astype(int))
+        assert d.max() <= 1 and (d > 0).mean() < 1e-3                  # bytes: equal except where a sum sits on a rounding boundary

@@ -230,7 +230,7 @@ def test_renders_of_one_scene_on_two_streams_overlap_safely(gpu):
     sc, cam, view = gpu.build_named_scene("cornell")
     try:
         jobs = [gpu.Settings(640, 480, 0, 10, 0, seed=31, sample_begin=0, sample_end=96), gpu.Settings(512, 512, 0, 10, 0, seed=32, sample_begin=7, sample_end=71)]
-        alone = [sc.render(cam, st)[0] for st in jobs]
+        alone, alone_stats = zip(*[sc.render(cam, st) for st in jobs])
         for rep in range(2):                                         # second pass: the cached tile orders of both streams are reused
             accs = [rd.new_accum(st.c.height, st.c.width, "cuda:0") for st in jobs]
             streams = [torch.cuda.Stream(), torch.cuda.Stream()] if rep == 0 else streams
@@ -241,6 +241,9 @@ def test_renders_of_one_scene_on_two_streams_overlap_safely(gpu):
             torch.cuda.synchronize()
             for acc, want in zip(accs, alone):
                 assert np.array_equal(acc.cpu().numpy(), want)
+            for side, want in zip(streams, alone_stats):             # the counters are per stream: overlapping renders do not add into each other's
+                got = sc.stats(side.cuda_stream)
+                assert (got["rays"], got["wave_iterations"], got["samples"]) == (want["rays"], want["wave_iterations"], want["samples"])
     finally:
         sc.close()
 
@@ -254,7 +257,7 @@ def test_wavefront_renders_on_two_streams_share_the_pool_in_order(gpu):
     sc, cam, view = gpu.build_named_scene("book1")
     try:
         jobs = [gpu.Settings(320, 200, 16, view.max_depth, view.integrator, seed=41), gpu.Settings(256, 256, 24, view.max_depth, view.integrator, seed=42)]
-        alone = [sc.render(cam, st)[0] for st in jobs]
+        alone, alone_stats = zip(*[sc.render(cam, st) for st in jobs])
         streams = [torch.cuda.Stream(), torch.cuda.Stream()]
         for rep in range(3):
             accs = [rd.new_accum(st.c.height, st.c.width, "cuda:0") for st in jobs]
@@ -265,6 +268,9 @@ def test_wavefront_renders_on_two_streams_share_the_pool_in_order(gpu):
             torch.cuda.synchronize()
             for acc, want in zip(accs, alone):
                 assert np.array_equal(acc.cpu().numpy(), want)
+            for side, want in zip(streams, alone_stats):             # ray counts too: k_wf_finish folds into the calling stream's counters
+                got = sc.stats(side.cuda_stream)
+                assert (got["rays"], got["samples"]) == (want["rays"], want["samples"])
     finally:
         sc.close()
 

@@ -121,10 +121,27 @@ int rtc_first_hit_f32(const rtc_scene *scene, const double *rays7, size_t n, dou
  * accum_rgba is W*H float4 = (sum R, sum G, sum B, sample count), row j=0 at the BOTTOM like the reference's
  * pixel index (main.c:157); the call ADDS to it, so successive calls with disjoint sample ranges accumulate
  * progressively.  rtc_render_device takes a DEVICE pointer (e.g. a torch tensor's data_ptr) and enqueues on
- * `stream` (a hipStream_t, NULL = default stream) without synchronising; rtc_render takes a HOST buffer. */
+ * `stream` (a hipStream_t, NULL = default stream) without synchronising; rtc_render takes a HOST buffer.
+ * EXCEPTION: the wavefront pipeline (kernel 3, the automatic choice for every scene flattened into a BVH) runs a host loop
+ * that reads the live-path count back every 8 bounces: the call BLOCKS the calling thread (holding the scene's mutex) until
+ * the last bounce has run and returns with only the final accumulate in flight on `stream`.  Small scenes (kernel 2) and the
+ * megakernel (kernel 1) only enqueue. */
 int rtc_render_device(const rtc_scene *scene, const camera *cam, const rtc_settings *settings,
                       float *accum_rgba_device, void *stream);
 int rtc_render(const rtc_scene *scene, const camera *cam, const rtc_settings *settings, float *accum_rgba_host);
+/* NO COUNTERPART IN THE REFERENCE (its CPU loop allocates freely: two mallocs per diffuse bounce, pdf.c:21-25).  For callers
+ * that cannot allocate -- code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc: rtc_render_device
+ * with the same arguments and the same kernels, but its scratch (ray counters, tile costs and order, per-chunk partial sums)
+ * lives in a file-scope device array of the library (17 MiB + 256 B per GPU, held until the process ends) instead of
+ * hipMalloc'ed per-stream buffers.  Calls no hipMalloc / hipFree / stream or event creation and touches no host heap.
+ * Limits: small scenes only (<= 64 rect/sphere leaves, solid textures, no media: kernel 0 or 2) -> RTC_ERR_SCENE otherwise;
+ * at most 131,072 tiles of 8x8 pixels (e.g. 3840 x 2160) -> RTC_ERR_ARG "image too large"; when W * H * chunks exceeds 2^20
+ * float4 of partial sums a tile's samples are run by fewer waves (float sums reassociated: relative 1e-5 against
+ * rtc_render_device, bit-identical otherwise).  No per-stream state is kept: rtc_render_stats does not see these calls and
+ * the tile order is probed on every call.  All calls on one GPU share the array: calls that OVERLAP on one GPU (two streams)
+ * race; calls on one stream, or ordered by events, are safe. */
+int rtc_render_device_noalloc(const rtc_scene *scene, const camera *cam, const rtc_settings *settings,
+                              float *accum_rgba_device, void *stream);
 /* Blocks until the last rtc_render_device on `stream` has finished and fills the counters. */
 int rtc_render_stats(const rtc_scene *scene, void *stream, rtc_stats *out);
 

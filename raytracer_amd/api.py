@@ -69,7 +69,7 @@ hittable_rect_new hittable_box_new hittable_moving_sphere_new bvh_node_init hitt
 hittable_rotate_init hittable_constant_medium_init hittable_constant_medium_init_c hittable_flip_face_init
 hittable_free camera_new camera_free camera_fields camera_get_ray write_color ray_color material_free texture_free rt_scene_build rt_scene_set_image_path rt_write_png rt_write_ppm_p3""".split()
 RTC_SYMBOLS = """rtc_init rtc_last_error rtc_device_name rtc_scene_build rtc_scene_flatten_only rtc_scene_save rtc_scene_load rtc_scene_load_host rtc_scene_free rtc_scene_num_prims
-rtc_scene_dump_leaves rtc_scene_bvh_info rtc_scene_dump_bvh rtc_first_hit_f64 rtc_first_hit_f32 rtc_primary_first_hit_f64 rtc_render_device rtc_render rtc_render_stats
+rtc_scene_dump_leaves rtc_scene_bvh_info rtc_scene_dump_bvh rtc_first_hit_f64 rtc_first_hit_f32 rtc_primary_first_hit_f64 rtc_render_device rtc_render_device_noalloc rtc_render rtc_render_stats
 rtc_tonemap_u8_device rtc_tonemap_u8 rtc_ray_colors rtc_kat make_scene free_scene render_scene render_scene_accumulate""".split()
 
 
@@ -147,6 +147,7 @@ def lib():
     L.rtc_primary_first_hit_f64.argtypes = [_P, _P, _dp, _dp, C.c_size_t, C.c_double, C.c_double, _P, _dp, _dp]
     L.rtc_render_device.argtypes = [_P, _P, C.POINTER(RtcSettings), _P, _P]
     L.rtc_render.argtypes = [_P, _P, C.POINTER(RtcSettings), _P]
+    L.rtc_render_device_noalloc.argtypes = [_P, _P, C.POINTER(RtcSettings), _P, _P]
     L.rtc_render_stats.argtypes = [_P, _P, C.POINTER(RtcStats)]
     L.rtc_tonemap_u8_device.argtypes = [_P, C.c_int, C.c_int, _P, _P]
     L.rtc_tonemap_u8.argtypes = [_P, C.c_int, C.c_int, _P]

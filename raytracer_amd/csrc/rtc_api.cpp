@@ -24,7 +24,9 @@
 namespace {
 
 thread_local std::string g_error;
-int fail(int code, const std::string &msg) { g_error = msg; return code; }
+thread_local const char *g_error_literal = nullptr;   // set by fail_literal: an error path that must not touch the heap
+int fail(int code, const std::string &msg) { g_error = msg; g_error_literal = nullptr; return code; }
+int fail_literal(int code, const char *msg) { g_error_literal = msg; return code; }
 #define HIP_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return fail(RTC_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_)); } while (0)
 
 struct DevBuf {
@@ -112,6 +114,37 @@ struct StreamState {
 
 }  // namespace
 
+// ---- scratch of the allocation-free entry point (rtc_render_device_noalloc) --------------------------------------------
+// Device memory the small-scene render needs beyond its inputs and outputs -- the ray / iteration counters, the cost and
+// order of the 8x8 tiles, the per-chunk partial sums -- as ONE file-scope device array instead of hipMalloc'ed buffers:
+// 256 B + 1 MiB + 16 MiB.  Every GPU the library runs on holds its own copy, at its own address, until the process ends.
+// In host code the array's NAME is only a handle for hipGetSymbolAddress (below); the address it yields, kept per device in
+// g_noalloc_ptr, is what kernels, memsets and copies are given.
+enum : size_t { RTC_NOALLOC_MAX_TILES = 1u << 17,          // 8x8 tiles: up to 3840 x 2160 (129,600 tiles)
+                RTC_NOALLOC_MAX_PARTIAL = 1u << 20,        // float4 partial sums: W * H * chunks, e.g. 1024 x 512 x 2
+                RTC_NOALLOC_COUNTER_BYTES = 256,
+                RTC_NOALLOC_BYTES = RTC_NOALLOC_COUNTER_BYTES + 2 * RTC_NOALLOC_MAX_TILES * sizeof(int) + RTC_NOALLOC_MAX_PARTIAL * 16 };
+static __device__ __align__(256) unsigned char scratch[RTC_NOALLOC_BYTES];
+namespace {
+enum { RTC_MAX_DEVICES = 64 };
+void *g_noalloc_ptr[RTC_MAX_DEVICES];      // device address of `scratch` on device d (nullptr: not asked yet)
+std::mutex g_noalloc_mu[RTC_MAX_DEVICES];  // serialises the ENQUEUE of calls on one device; overlapping execution on two streams still races
+std::mutex g_noalloc_init_mu;
+// once per device, with that device current (rtc_init, or the entry point's first call on the device)
+int noalloc_scratch(void **out) {
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= RTC_MAX_DEVICES) return fail_literal(RTC_ERR_DEVICE, "rtc_render_device_noalloc: no current HIP device (or its ordinal is >= 64)");
+    std::lock_guard<std::mutex> lk(g_noalloc_init_mu);
+    if (!g_noalloc_ptr[dev]) {
+        void *ptr = nullptr;
+        if (hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)) != hipSuccess || !ptr) { (void)hipGetLastError(); return fail_literal(RTC_ERR_DEVICE, "rtc_render_device_noalloc: hipGetSymbolAddress(scratch) failed on this device"); }
+        g_noalloc_ptr[dev] = ptr;
+    }
+    *out = g_noalloc_ptr[dev];
+    return RTC_OK;
+}
+}  // namespace
+
 struct rtc_scene {
     FlatScene flat;
     int device = -1;
@@ -129,7 +162,7 @@ struct rtc_scene {
 
 extern "C" {
 
-const char *rtc_last_error(void) { return g_error.c_str(); }
+const char *rtc_last_error(void) { return g_error_literal ? g_error_literal : g_error.c_str(); }
 
 int rtc_init(void) {
     int n = 0;
@@ -138,7 +171,8 @@ int rtc_init(void) {
     int dev = 0; HIP_TRY(hipGetDevice(&dev));
     hipDeviceProp_t prop; HIP_TRY(hipGetDeviceProperties(&prop, dev));
     if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) return fail(RTC_ERR_DEVICE, std::string("kernels are built for gfx950, device is ") + prop.gcnArchName);
-    return RTC_OK;
+    void *scratch_ptr = nullptr;               // the allocation-free entry point's scratch: resolve its address on this device now
+    return noalloc_scratch(&scratch_ptr);
 }
 const char *rtc_device_name(void) {
     static thread_local char name[256];
@@ -485,6 +519,57 @@ int rtc_render_device(const rtc_scene *scene_c, const camera *cam, const rtc_set
     HIP_TRY(hipEventRecord(ss.ev1, stream));
     ss.samples = (uint64_t)st->width * st->height * (uint64_t)(st->sample_end - st->sample_begin);
     ss.launches = 1; ss.pending = true;
+    return RTC_OK;
+}
+
+// rtc_render_device for callers that cannot allocate (HIP graph capture, serving loops, harnesses that forbid hipMalloc): the
+// same kernels, their scratch in the file-scope device array above.  No hipMalloc / hipFree / event or stream creation, no
+// host heap either (no per-stream state is kept: rtc_render_stats does not see these calls).  Small scenes only.
+int rtc_render_device_noalloc(const rtc_scene *scene_c, const camera *cam, const rtc_settings *st, float *accum_dev, void *stream_v) {
+    const rtc_scene *s = scene_c;
+    if (!s || !cam || !accum_dev || !st) return fail_literal(RTC_ERR_ARG, "rtc_render_device_noalloc: null argument");
+    if (s->device < 0) return fail_literal(RTC_ERR_DEVICE, "rtc_render_device_noalloc: the scene has no device tables (flattened on the host only)");
+    int cur = -1;
+    if (hipGetDevice(&cur) != hipSuccess || cur != s->device) return fail_literal(RTC_ERR_DEVICE, "rtc_render_device_noalloc: the scene lives on another HIP device than the current one");
+    if (st->width < 2 || st->height < 2 || st->sample_end < st->sample_begin || st->sample_begin < 0 || st->max_depth < 0 || st->max_depth > 4096 ||
+        st->integrator < 0 || st->integrator > 2) return fail_literal(RTC_ERR_ARG, "rtc_render_device_noalloc: bad settings (size >= 2x2, 0 <= sample_begin <= sample_end, 0 <= max_depth <= 4096, integrator 0..2)");
+    if (st->kernel != 0 && st->kernel != 2) return fail_literal(RTC_ERR_SCENE, "rtc_render_device_noalloc: only the small-scene kernel (kernel 0 or 2) has an allocation-free form");
+    if (s->small.n_leaves <= 0) return fail_literal(RTC_ERR_SCENE, "rtc_render_device_noalloc: needs a small scene (<= 64 rect/sphere leaves, solid textures, no media)");
+    const long long tiles_x = (st->width + 7) / 8, tiles_y = (st->height + 7) / 8;
+    if (tiles_x * tiles_y > (long long)RTC_NOALLOC_MAX_TILES)
+        return fail_literal(RTC_ERR_ARG, "rtc_render_device_noalloc: image too large for the static scratch (at most 131,072 tiles of 8x8 pixels, e.g. 3840 x 2160)");
+    hipPointerAttribute_t attr;                 // a host pointer must not reach a kernel
+    if (hipPointerGetAttributes(&attr, accum_dev) != hipSuccess || attr.type == hipMemoryTypeHost || attr.type == hipMemoryTypeUnregistered ||
+        (attr.type == hipMemoryTypeDevice && attr.device != cur)) { (void)hipGetLastError(); return fail_literal(RTC_ERR_ARG, "rtc_render_device_noalloc: accum_dev is not device memory of the current device"); }
+    void *base = nullptr;
+    if (int rc = noalloc_scratch(&base)) return rc;
+    hipStream_t stream = (hipStream_t)stream_v;
+    RenderParams p; std::memset(&p, 0, sizeof p);
+    p.width = st->width; p.height = st->height; p.s_begin = st->sample_begin; p.s_end = st->sample_end;
+    p.max_depth = st->max_depth; p.integrator = st->integrator;
+    p.seed_lo = (uint32_t)st->seed; p.seed_hi = (uint32_t)(st->seed >> 32);
+    p.light_weight = s->flat.lights.empty() ? 0.0f : (float)st->mixture_light_weight;
+    p.light_weight_each = s->flat.lights.empty() ? 0.0f : p.light_weight / (float)s->flat.lights.size(); p.cosine_weight = 1.0f - p.light_weight;
+    p.tiles_x = (int)tiles_x; p.tiles_y = (int)tiles_y; p.n_tiles = p.tiles_x * p.tiles_y;
+    const CameraT<float> camf = camera_tables<float>(cam);
+    p.use_time = camf.time0 != camf.time1;
+    // layout of the scratch: counters | tile cost + order | partial planes
+    unsigned long long *counters = (unsigned long long *)base;
+    int *tile_scratch = (int *)((char *)base + RTC_NOALLOC_COUNTER_BYTES);
+    float4 *partial = (float4 *)((char *)base + RTC_NOALLOC_COUNTER_BYTES + 2 * RTC_NOALLOC_MAX_TILES * sizeof(int));
+    // the chunking rule of rtc_render_device, then as many chunks as fit the partial planes: with the same chunking the sums are
+    // bit-identical to rtc_render_device's, with fewer chunks they differ by float reassociation only
+    int log2_chunks = 0;
+    const int spp = p.s_end - p.s_begin;
+    while (log2_chunks < 3 && ((long long)p.n_tiles << log2_chunks) < 60000 && (spp >> (log2_chunks + 1)) >= 32) ++log2_chunks;
+    while (log2_chunks > 0 && (((size_t)p.width * p.height) << log2_chunks) > RTC_NOALLOC_MAX_PARTIAL) --log2_chunks;
+    std::lock_guard<std::mutex> lk(g_noalloc_mu[cur]);
+    // the array keeps the last call's contents: the counters must start at zero; tile costs, order and partial planes are
+    // fully rewritten by the kernels before they are read (probe -> sort -> render -> combine)
+    if (hipMemsetAsync(counters, 0, RTC_NOALLOC_COUNTER_BYTES, stream) != hipSuccess) { (void)hipGetLastError(); return fail_literal(RTC_ERR_DEVICE, "rtc_render_device_noalloc: hipMemsetAsync failed"); }
+    int ordered = 0;                            // no per-stream cache here: the tile order is probed on every call
+    if (launch_pathtrace_small(s->small, s->f32.view, camf, p, (float4 *)accum_dev, counters, tile_scratch, &ordered, log2_chunks ? partial : nullptr, log2_chunks, stream) != hipSuccess)
+        return fail_literal(RTC_ERR_DEVICE, "rtc_render_device_noalloc: kernel launch failed");
     return RTC_OK;
 }
 

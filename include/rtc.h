@@ -156,7 +156,8 @@ int rtc_ray_colors(const rtc_scene *scene, const double *rays7, size_t n, const 
 /* TEST-ONLY known-answer probe: evaluates, on the device and for n supplied inputs, the functions the production kernels
  * call, so that they can be compared with the reference's outputs for the same inputs (tests/golden/unit_vectors.npz).
  * Doubles in and out (converted to the kernels' FP32 on the device).  `what`:
- *   0 Philox4x32-7 block of (pixel, sample, tag, key lo, key hi)  -> 4 raw words          (replaces rand(), utils.h:23)
+ *   0 Philox4x32-7 block of (pixel, sample, tag, seed lo, seed hi) -> 4 raw words: counter = (pixel, sample, tag, seed lo),
+ *     key = ("RTC1", seed hi)                                                              (replaces rand(), utils.h:23)
  *   1 light-list pdf, general kernels: origin(3) dir(3) -> pdf       (hittable_list.c:165-172, hittable.c:760-788)
  *   2 the same as the small-scene kernel computes it (unit direction, folded hit tests)
  *   3 cosine pdf = lambertian scattering pdf: normal(3) dir(3) -> pdf (pdf.c:100-103, material.c:205-208)

@@ -37,8 +37,11 @@ struct Rng4 { float x, y, z, w; };
 #define RT_TAG_CAMERA 0xFFFFFFFFu
 #define RT_TAG_TIME 0xFFFFFFFEu
 #define RT_TAG_MEDIA 0x80000000u
-RT_DEV Rng4 rng_block(uint32_t pixel, uint32_t sample, uint32_t tag, uint32_t k0, uint32_t k1) {
-    const U4 b = philox4x32(pixel, sample, tag, 0x52544331u /* "RTC1" */, k0, k1);
+// Counter = (pixel, sample, tag, seed low word), key = ("RTC1", seed high word).  The seed's low word rides in the COUNTER so
+// that key word 0 is a compile-time constant: its seven round keys become literals instead of seven more SGPRs held through
+// the bounce loop (the small-scene kernel spilled 11 SGPRs to lanes with the seed in the key, 2 without: -2 %, r02a).
+RT_DEV Rng4 rng_block(uint32_t pixel, uint32_t sample, uint32_t tag, uint32_t seed_lo, uint32_t seed_hi) {
+    const U4 b = philox4x32(pixel, sample, tag, seed_lo, 0x52544331u /* "RTC1" */, seed_hi);
     Rng4 r; r.x = u01(b.x); r.y = u01(b.y); r.z = u01(b.z); r.w = u01(b.w); return r;
 }
 

@@ -15,6 +15,9 @@ struct RenderParams {
     float light_weight_each, cosine_weight;   // light_weight / number of lights (0 without lights), 1 - light_weight: launch constants of pdf.c:119-121
     int tiles_x, tiles_y, n_tiles;   // 8x8-pixel tiles, one wave each
     int use_time;                    // camera shutter open (time0 != time1)
+    // pinhole camera of the small-scene kernel, folded on the host: direction(px + jx, py + jy) = base + hs (px + jx) + vs (py + jy)
+    // with base = lower_left_corner - origin, hs = horizontal / (W - 1), vs = vertical / (H - 1)   (camera.c:46-53, main.c:150-151)
+    float cam_base[3], cam_hs[3], cam_vs[3];
 };
 
 hipError_t launch_first_hit_f64(const SceneT<double> &sc, const double *rays7, size_t n, double tmin, double tmax,

@@ -89,7 +89,7 @@ __global__ void __launch_bounds__(256) k_kat(SceneT<float> sc, int what, const d
     auto v3at = [&](int k) { return f3mk((float)a[k], (float)a[k + 1], (float)a[k + 2]); };
     switch (what) {
     case RTC_KAT_PHILOX: {       // the raw block behind rng_block(pixel, sample, tag, k0, k1)
-        const U4 b = philox4x32((uint32_t)a[0], (uint32_t)a[1], (uint32_t)a[2], 0x52544331u, (uint32_t)a[3], (uint32_t)a[4]);
+        const U4 b = philox4x32((uint32_t)a[0], (uint32_t)a[1], (uint32_t)a[2], (uint32_t)a[3], 0x52544331u, (uint32_t)a[4]);   // = rng_block's block
         o[0] = b.x; o[1] = b.y; o[2] = b.z; o[3] = b.w; break;
     }
     case RTC_KAT_LIGHT_PDF: o[0] = sc.n_lights > 0 ? light_list_pdf(sc, v3at(0), v3at(3)) : 0.0; break;   // hittable_list.c:165-172

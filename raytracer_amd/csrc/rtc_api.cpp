@@ -468,6 +468,7 @@ int rtc_render_device(const rtc_scene *scene_c, const camera *cam, const rtc_set
     p.tiles_x = (st->width + 7) / 8; p.tiles_y = (st->height + 7) / 8; p.n_tiles = p.tiles_x * p.tiles_y;
     const CameraT<float> camf = camera_tables<float>(cam);
     p.use_time = camf.time0 != camf.time1;
+    for (int k = 0; k < 3; k++) { p.cam_base[k] = camf.llc[k] - camf.origin[k]; p.cam_hs[k] = camf.horizontal[k] / (float)(p.width - 1); p.cam_vs[k] = camf.vertical[k] / (float)(p.height - 1); }
     if (!ss.stats.p) { const unsigned long long zero[4] = {0, 0, 0, 0}; HIP_TRY(ss.stats.upload(zero, sizeof zero)); }
     unsigned long long *const stats = (unsigned long long *)ss.stats.p;
     HIP_TRY(hipMemsetAsync(stats, 0, 4 * sizeof(unsigned long long), stream));
@@ -553,6 +554,7 @@ int rtc_render_device_noalloc(const rtc_scene *scene_c, const camera *cam, const
     p.tiles_x = (int)tiles_x; p.tiles_y = (int)tiles_y; p.n_tiles = p.tiles_x * p.tiles_y;
     const CameraT<float> camf = camera_tables<float>(cam);
     p.use_time = camf.time0 != camf.time1;
+    for (int k = 0; k < 3; k++) { p.cam_base[k] = camf.llc[k] - camf.origin[k]; p.cam_hs[k] = camf.horizontal[k] / (float)(p.width - 1); p.cam_vs[k] = camf.vertical[k] / (float)(p.height - 1); }
     // layout of the scratch: counters | tile cost + order | partial planes
     unsigned long long *counters = (unsigned long long *)base;
     int *tile_scratch = (int *)((char *)base + RTC_NOALLOC_COUNTER_BYTES);

@@ -48,14 +48,15 @@ def test_host_philox_is_the_published_generator():
 
 
 def test_device_philox7_block(cornell):
-    """rng_block's raw words (7 rounds, counter word 3 = "RTC1") for pixel / sample / tag / key edge values, bit for bit."""
+    """rng_block's raw words (7 rounds; counter = pixel, sample, tag, seed low word; key = "RTC1", seed high word) for edge
+    values of all five inputs, bit for bit."""
     sc = cornell[0]
     rng = np.random.default_rng(5)
     inp = rng.integers(0, 2 ** 32, (4096, 5), dtype=np.uint64)
     inp[:8] = [[0, 0, 0, 0, 0], [0xFFFFFFFF] * 5, [1, 0, 0, 0, 0], [0, 1, 0, 0, 0], [0, 0, 0xFFFFFFFF, 0, 0], [0, 0, 0xFFFFFFFE, 0, 0],
                [2073599, 255, 9, 0, 0], [0, 0, 0x80000000, 1, 2]]
     got = sc.kat(PHILOX, inp.astype(np.float64))
-    want = philox4x32_host(inp[:, 0], inp[:, 1], inp[:, 2], np.full(len(inp), 0x52544331, dtype=np.uint64), inp[:, 3], inp[:, 4], 7)
+    want = philox4x32_host(inp[:, 0], inp[:, 1], inp[:, 2], inp[:, 3], np.full(len(inp), 0x52544331, dtype=np.uint64), inp[:, 4], 7)
     assert np.array_equal(got.astype(np.uint64), want)
 
 

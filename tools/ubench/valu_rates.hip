@@ -7,11 +7,12 @@
 
 #define CHK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
 constexpr int ITERS = 4096;
+static int g_repeat = 1;   // calibration mode: the kernel body is run g_repeat times longer (launch ramp and tail become negligible)
 
-template <int OP> __global__ void __launch_bounds__(256) k(float *out, float seed) {
+template <int OP> __global__ void __launch_bounds__(256) k(float *out, float seed, int repeat) {
     float a[8]; uint32_t u[8]; uint64_t w[8];
     for (int i = 0; i < 8; i++) { a[i] = seed + threadIdx.x + i; u[i] = (uint32_t)(threadIdx.x * 2654435761u + i); w[i] = u[i]; }
-    for (int it = 0; it < ITERS; ++it) {
+    for (int it = 0; it < ITERS * repeat; ++it) {
 #pragma unroll
         for (int i = 0; i < 8; i++) {
             if (OP == 0) a[i] = __builtin_fmaf(a[i], 1.0001f, 0.5f);
@@ -34,19 +35,22 @@ template <int OP> int run(const char *name, int instr_per_iter_per_chain) {
     const int blocks = 256 * 8;    // 8 blocks of 256 per CU = 8 waves/SIMD if registers allow
     float *out; CHK(hipMalloc(&out, blocks * 256 * sizeof(float)));
     hipEvent_t e0, e1; CHK(hipEventCreate(&e0)); CHK(hipEventCreate(&e1));
-    hipLaunchKernelGGL(k<OP>, dim3(blocks), dim3(256), 0, 0, out, 1.5f);
+    hipLaunchKernelGGL(k<OP>, dim3(blocks), dim3(256), 0, 0, out, 1.5f, g_repeat);
     CHK(hipDeviceSynchronize());
     CHK(hipEventRecord(e0));
-    hipLaunchKernelGGL(k<OP>, dim3(blocks), dim3(256), 0, 0, out, 1.5f);
+    hipLaunchKernelGGL(k<OP>, dim3(blocks), dim3(256), 0, 0, out, 1.5f, g_repeat);
     CHK(hipEventRecord(e1)); CHK(hipEventSynchronize(e1));
     float ms; CHK(hipEventElapsedTime(&ms, e0, e1));
-    const double wave_instr = (double)blocks * 4 * ITERS * 8 * instr_per_iter_per_chain;
+    const double wave_instr = (double)blocks * 4 * ITERS * g_repeat * 8 * instr_per_iter_per_chain;
     const double simd_cycles = ms * 1e-3 * 2.4e9 * 1024;   // 256 CU x 4 SIMD at 2.4 GHz nominal
     printf("%-28s %8.3f ms  %6.2f cycles per wave-instruction per SIMD (nominal 2.4 GHz)\n", name, ms, simd_cycles / wave_instr);
     CHK(hipFree(out));
     return 0;
 }
-int main() {
+int main(int argc, char **argv) {
+    // `valu_rates calib`: the pure v_fma_f32 loop alone, 64x longer, for reading SQ_INSTS_VALU / SQ_ACTIVE_INST_VALU / GRBM_GUI_ACTIVE
+    // under rocprofv3 --pmc: the loop that must read "VALU issue utilisation 1.0" 
+    if (argc > 1 && argv[1][0] == 'c') { g_repeat = 64; run<0>("v_fma_f32 (calibration)", 1); run<0>("v_fma_f32 (calibration)", 1); return 0; }
     run<0>("v_fma_f32", 1); run<1>("v_rcp_f32", 1); run<2>("v_sqrt_f32", 1); run<3>("v_sin_f32", 1);
     run<4>("v_mad_u64_u32", 1); run<5>("v_mul_lo_u32(+add)", 2); run<6>("v_mul_hi_u32(+xor)", 2); run<7>("xor/shift/add (3)", 3);
     run<8>("cmp+cndmask+mul+add", 4); run<9>("v_mul_u32_u24", 1);

@@ -21,7 +21,9 @@ struct FlatScene {
     std::vector<int> leaf_prims;
     std::vector<BLeaf> bleaves;     // FP32 traversal leaves, one per slot of leaf_prims
     std::vector<SmallShade> leaf_shade;   // shading record per slot of leaf_prims (rtc_tables.h SmallShade, RTC_SF_GENERAL)
-    int bvh_depth = 0;              // levels of the production BVH (root = 1): bounds the traversal stack
+    int bvh_depth = 0;              // levels of the binary BVH (root = 1)
+    std::vector<BvhNode4> nodes4;   // what the GPU traverses: the binary tree collapsed to four children per node (build_bvh4); derived, not stored in scene files
+    int bvh_stack = 0;              // traversal stack entries the four-child tree needs (<= RTC_BVH_MAX_STACK)
     std::vector<int> box_first;     // first primitive of every hittable box (its 6 sides follow in creation order)
     std::vector<int> box_slots;     // leaf slots where an axis-aligned box record starts (it owns 6 slots: BLeaf, rtc_tables.h)
     std::vector<RefStep> ref_steps; // the reference's own traversal, depth-first (FP64 check path)
@@ -43,6 +45,10 @@ struct FlatScene {
     double background[3] = {0, 0, 0};
     std::string error;
 };
+
+// nodes -> nodes4 + bvh_stack (deterministic; also run after a scene file is loaded).  False + out.error when the tree needs
+// a deeper traversal stack than RTC_BVH_MAX_STACK.
+bool build_bvh4(FlatScene &out);
 
 // Walks world/lights once.  Primitive order = the reference's traversal order (list order, box sides in creation
 // order, BVH members in the order recorded by bvh_node_init).  Builds the BVH when the scene has more than

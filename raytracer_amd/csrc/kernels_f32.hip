@@ -19,7 +19,7 @@ namespace {
 template <bool BVH>
 __global__ void __launch_bounds__(256) k_pathtrace_mega(SceneT<float> sc, CameraT<float> cam, RenderParams P,
                                                          float4 *__restrict__ accum, unsigned long long *__restrict__ ray_counter) {
-    extern __shared__ int lds_stack[];                                     // BVH: sc.bvh_depth entries per lane
+    extern __shared__ int lds_stack[];                                     // BVH: sc.bvh_stack entries per lane
     const int lane = threadIdx.x & 63;
     int block = blockIdx.x;
     if (BVH) {   // blocks with equal (id % 8) share an XCD and its L2: give each XCD one contiguous band of tiles
@@ -61,7 +61,7 @@ __global__ void __launch_bounds__(256) k_pathtrace_mega(SceneT<float> sc, Camera
             MediumSampler medium{&sc, &ps.ray, 0.001f, pixel, s_cur, (uint32_t)depth, P.seed_lo, P.seed_hi, 0};
             HitT<float> h; int hit_src;                                    // hit_src: what `src` must hold for the next ray
             if (BVH) {
-                LdsStack stack(lds_stack + threadIdx.x, 256, sc.bvh_depth);
+                LdsStack stack(lds_stack + threadIdx.x, 256, sc.bvh_stack);
                 const HitS hs = bvh_closest_hit(sc, ps.ray, 0.001f, Mth<float>::inf(), stack, medium, src);   // ray.c:56
                 h.t = hs.t; h.prim = hs.prim; hit_src = hs.slot;
             } else {
@@ -107,14 +107,14 @@ __global__ void __launch_bounds__(256) k_pathtrace_mega(SceneT<float> sc, Camera
 template <bool BVH>
 __global__ void __launch_bounds__(256) k_first_hit_f32(SceneT<float> sc, const float *__restrict__ rays7, size_t n, float tmin, float tmax,
                                                         int32_t *__restrict__ prim_id, float *__restrict__ t_out) {
-    extern __shared__ int lds_stack[];                                     // BVH: sc.bvh_depth entries per lane
+    extern __shared__ int lds_stack[];                                     // BVH: sc.bvh_stack entries per lane
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = i < n;
     const float *a = rays7 + 7 * (live ? i : 0);
     RayT<float> r; r.o = f3mk(a[0], a[1], a[2]); r.d = f3mk(a[3], a[4], a[5]); r.time = a[6];
     NoMedium32 nv;
     HitT<float> h;
-    if (BVH) { LdsStack stack(lds_stack + threadIdx.x, 256, sc.bvh_depth); const HitS hs = bvh_closest_hit(sc, r, tmin, tmax, stack, nv); h.t = hs.t; h.prim = hs.prim; }
+    if (BVH) { LdsStack stack(lds_stack + threadIdx.x, 256, sc.bvh_stack); const HitS hs = bvh_closest_hit(sc, r, tmin, tmax, stack, nv); h.t = hs.t; h.prim = hs.prim; }
     else h = closest_hit_linear<float>(sc, r, tmin, tmax, nv);
     if (live) { prim_id[i] = h.prim; t_out[i] = h.prim >= 0 ? h.t : 0.0f; }
 }
@@ -142,14 +142,14 @@ hipError_t launch_pathtrace_mega(const SceneT<float> &sc, const CameraT<float> &
                                  float4 *accum, unsigned long long *ray_counter, hipStream_t stream) {
     if (p.n_tiles <= 0 || p.s_end <= p.s_begin) return hipSuccess;
     const unsigned blocks = (unsigned)((p.n_tiles + 3) / 4);
-    if (sc.n_nodes > 0) hipLaunchKernelGGL(k_pathtrace_mega<true>, dim3(blocks), dim3(256), (size_t)sc.bvh_depth * 256 * sizeof(int), stream, sc, cam, p, accum, ray_counter);
+    if (sc.n_nodes > 0) hipLaunchKernelGGL(k_pathtrace_mega<true>, dim3(blocks), dim3(256), (size_t)sc.bvh_stack * 256 * sizeof(int), stream, sc, cam, p, accum, ray_counter);
     else hipLaunchKernelGGL(k_pathtrace_mega<false>, dim3(blocks), dim3(256), 0, stream, sc, cam, p, accum, ray_counter);
     return hipGetLastError();
 }
 hipError_t launch_first_hit_f32(const SceneT<float> &sc, const float *rays7, size_t n, float tmin, float tmax, int32_t *prim_id, float *t, hipStream_t stream) {
     if (n == 0) return hipSuccess;
     const unsigned blocks = (unsigned)((n + 255) / 256);
-    if (sc.n_nodes > 0) hipLaunchKernelGGL(k_first_hit_f32<true>, dim3(blocks), dim3(256), (size_t)sc.bvh_depth * 256 * sizeof(int), stream, sc, rays7, n, tmin, tmax, prim_id, t);
+    if (sc.n_nodes > 0) hipLaunchKernelGGL(k_first_hit_f32<true>, dim3(blocks), dim3(256), (size_t)sc.bvh_stack * 256 * sizeof(int), stream, sc, rays7, n, tmin, tmax, prim_id, t);
     else hipLaunchKernelGGL(k_first_hit_f32<false>, dim3(blocks), dim3(256), 0, stream, sc, rays7, n, tmin, tmax, prim_id, t);
     return hipGetLastError();
 }

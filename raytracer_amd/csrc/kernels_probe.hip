@@ -17,7 +17,7 @@ namespace {
 template <bool BVH>
 __global__ void __launch_bounds__(256) k_ray_colors(SceneT<float> sc, RenderParams P, const float *__restrict__ rays7, unsigned n, unsigned chunks,
                                                      double *__restrict__ rgb_sum, unsigned long long *__restrict__ ray_counter) {
-    extern __shared__ int lds_stack[];                                     // BVH: sc.bvh_depth entries per lane
+    extern __shared__ int lds_stack[];                                     // BVH: sc.bvh_stack entries per lane
     const unsigned gid = blockIdx.x * blockDim.x + threadIdx.x;
     const unsigned i = gid / chunks, c = gid % chunks;
     const bool valid = i < n;
@@ -42,7 +42,7 @@ __global__ void __launch_bounds__(256) k_ray_colors(SceneT<float> sc, RenderPara
             MediumSampler medium{&sc, &ps.ray, 0.001f, i, s_cur, (uint32_t)depth, P.seed_lo, P.seed_hi, 0};
             HitT<float> h; int hit_src;
             if (BVH) {
-                LdsStack stack(lds_stack + threadIdx.x, 256, sc.bvh_depth);
+                LdsStack stack(lds_stack + threadIdx.x, 256, sc.bvh_stack);
                 const HitS hs = bvh_closest_hit(sc, ps.ray, 0.001f, Mth<float>::inf(), stack, medium, src);   // ray.c:56
                 h.t = hs.t; h.prim = hs.prim; hit_src = hs.slot;
             } else {
@@ -118,7 +118,7 @@ hipError_t launch_ray_colors(const SceneT<float> &sc, const RenderParams &p, con
     const unsigned long long lanes = (unsigned long long)n * chunks;
     if (chunks == 0 || lanes > (1ull << 31)) return hipErrorInvalidValue;
     const unsigned blocks = (unsigned)((lanes + 255) / 256);
-    if (sc.n_nodes > 0) hipLaunchKernelGGL(k_ray_colors<true>, dim3(blocks), dim3(256), (size_t)sc.bvh_depth * 256 * sizeof(int), stream, sc, p, rays7, n, chunks, rgb_sum, ray_counter);
+    if (sc.n_nodes > 0) hipLaunchKernelGGL(k_ray_colors<true>, dim3(blocks), dim3(256), (size_t)sc.bvh_stack * 256 * sizeof(int), stream, sc, p, rays7, n, chunks, rgb_sum, ray_counter);
     else hipLaunchKernelGGL(k_ray_colors<false>, dim3(blocks), dim3(256), 0, stream, sc, p, rays7, n, chunks, rgb_sum, ray_counter);
     return hipGetLastError();
 }

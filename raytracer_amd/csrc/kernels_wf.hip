@@ -113,7 +113,7 @@ constexpr int kWfStripes = 64;   // cache lines each statistic is striped over
 constexpr int kWfExtendBlock = RT_WF_EXTEND_BLOCK;
 template <int MEDIA, int KINDS>
 __global__ void __launch_bounds__(kWfExtendBlock) __attribute__((amdgpu_waves_per_eu(MEDIA == 2 ? 6 : 8))) k_wf_extend(SceneT<float> sc, RenderParams P, WfBuffers B, int cur, unsigned n_list) {
-    extern __shared__ int lds_stack[];                               // sc.bvh_depth entries per lane
+    extern __shared__ int lds_stack[];                               // sc.bvh_stack entries per lane
     const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
     const int slot = i < n_list ? B.active[cur][i] : -1;
     const bool live = slot >= 0;
@@ -132,7 +132,7 @@ __global__ void __launch_bounds__(kWfExtendBlock) __attribute__((amdgpu_waves_pe
             medium.sc = &sc; medium.ray = &r; medium.tmin = 0.001f; medium.pixel = (uint32_t)(py * P.width + px); medium.sample = sd & 0xffffffu; medium.bounce = sd >> 24;
             medium.k0 = P.seed_lo; medium.k1 = P.seed_hi; medium.draws = 0;
         }
-        LdsStack stack(lds_stack + threadIdx.x, kWfExtendBlock, sc.bvh_depth);
+        LdsStack stack(lds_stack + threadIdx.x, kWfExtendBlock, sc.bvh_stack);
         const HitS h = bvh_closest_hit<KINDS>(sc, r, 0.001f, Mth<float>::inf(), stack, medium, src_slot);   // ray.c:56
         B.hit[slot] = make_float2(h.t, __int_as_float(h.slot));
         const uint32_t lm = h.slot >= 0 ? sc.bleaves[h.slot].meta : 0u;
@@ -310,7 +310,7 @@ hipError_t launch_wf_bounce(const SceneT<float> &sc, const CameraT<float> &cam, 
                             int cur, unsigned n_list, hipStream_t stream) {
     if (n_list == 0) return hipSuccess;
     const unsigned blocks = (n_list + kWfExtendBlock - 1) / kWfExtendBlock;
-    const size_t lds = (size_t)sc.bvh_depth * kWfExtendBlock * sizeof(int);
+    const size_t lds = (size_t)sc.bvh_stack * kWfExtendBlock * sizeof(int);
     if (sc.media_kind == 0 && sc.leaf_kinds == RTC_KIND_SPHERE) hipLaunchKernelGGL((k_wf_extend<0, RTC_KIND_SPHERE>), dim3(blocks), dim3(kWfExtendBlock), lds, stream, sc, p, b, cur, n_list);
     else if (sc.media_kind == 0) hipLaunchKernelGGL((k_wf_extend<0, RTC_KIND_ALL>), dim3(blocks), dim3(kWfExtendBlock), lds, stream, sc, p, b, cur, n_list);
     else if (sc.media_kind == 1) hipLaunchKernelGGL((k_wf_extend<1, RTC_KIND_ALL>), dim3(blocks), dim3(kWfExtendBlock), lds, stream, sc, p, b, cur, n_list);

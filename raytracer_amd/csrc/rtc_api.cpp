@@ -14,6 +14,9 @@
 #include <vector>
 
 #include "kernels.h"
+#ifndef RT_BVH4
+#define RT_BVH4 0   // rt_core.hpp: 1 = the four-child-tree A/B build
+#endif
 // hip_runtime.h declares a class template named `texture` (legacy texture references); the host API's opaque
 // `struct texture` (reference name, texture.h:20) is renamed inside this translation unit only.
 #define texture rtc_host_texture
@@ -43,7 +46,7 @@ struct DevBuf {
 };
 
 template <typename R> struct DeviceTables {
-    DevBuf prims, bprims, ops, chains, materials, textures, lights, perlin_vec, perlin_perm, images, image_data, nodes, leaf_prims, bleaves, leaf_shade, ref_steps, ref_boxes;
+    DevBuf prims, bprims, ops, chains, materials, textures, lights, perlin_vec, perlin_perm, images, image_data, nodes, nodes4, leaf_prims, bleaves, leaf_shade, ref_steps, ref_boxes;
     SceneT<R> view;
     bool ready = false;
 };
@@ -65,9 +68,16 @@ template <typename R> hipError_t upload_tables(const FlatScene &fs, DeviceTables
     std::vector<LightT<R>> lights; for (const auto &x : fs.lights) lights.push_back(conv<R>(x));
     std::vector<R> pvec = convert_vec<R>(fs.perlin_vec);
     UP(prims, prims); UP(bprims, bprims); UP(ops, ops); UP(chains, fs.chains); UP(materials, mats); UP(textures, texs); UP(lights, lights);
-    UP(perlin_vec, pvec); UP(perlin_perm, fs.perlin_perm); UP(images, fs.images); UP(image_data, fs.image_data); UP(nodes, fs.nodes); UP(leaf_prims, fs.leaf_prims);
+    UP(perlin_vec, pvec); UP(perlin_perm, fs.perlin_perm); UP(images, fs.images); UP(image_data, fs.image_data); UP(leaf_prims, fs.leaf_prims);
     if (with_ref_steps) { UP(ref_steps, fs.ref_steps); UP(ref_boxes, fs.ref_boxes); }
-    else { UP(bleaves, fs.bleaves); UP(leaf_shade, fs.leaf_shade); }
+    else {
+#if RT_BVH4   // A/B build (rt_core.hpp): the four-child table instead of the binary one
+        UP(nodes4, fs.nodes4);
+#else
+        UP(nodes, fs.nodes);
+#endif
+        UP(bleaves, fs.bleaves); UP(leaf_shade, fs.leaf_shade);
+    }
 #undef UP
     SceneT<R> &v = dt.view;
     v.prims = (const PrimT<R> *)dt.prims.p; v.n_prims = (int)fs.prims.size();
@@ -78,11 +88,15 @@ template <typename R> hipError_t upload_tables(const FlatScene &fs, DeviceTables
     v.lights = (const LightT<R> *)dt.lights.p; v.n_lights = (int)fs.lights.size();
     v.perlin_vec = (const R *)dt.perlin_vec.p; v.perlin_perm = (const int *)dt.perlin_perm.p;
     v.images = (const ImageDesc *)dt.images.p; v.image_data = (const unsigned char *)dt.image_data.p;
-    v.nodes = (const BvhNode *)dt.nodes.p; v.leaf_prims = (const int *)dt.leaf_prims.p; v.n_nodes = (int)fs.nodes.size();
+    v.nodes = (const BvhNode *)dt.nodes.p; v.nodes4 = (const BvhNode4 *)dt.nodes4.p; v.leaf_prims = (const int *)dt.leaf_prims.p; v.n_nodes = (int)fs.nodes.size();
     v.bleaves = (const BLeaf *)dt.bleaves.p; v.leaf_shade = (const SmallShade *)dt.leaf_shade.p;
     v.ref_steps = (const RefStep *)dt.ref_steps.p; v.ref_boxes = (const double *)dt.ref_boxes.p;
     v.n_ref_steps = with_ref_steps ? (int)fs.ref_steps.size() : 0;
-    v.bvh_depth = fs.bvh_depth < 1 ? 1 : (fs.bvh_depth > RTC_BVH_MAX_DEPTH ? RTC_BVH_MAX_DEPTH : fs.bvh_depth);
+#if RT_BVH4
+    v.bvh_stack = fs.bvh_stack < 1 ? 1 : fs.bvh_stack;
+#else
+    v.bvh_stack = fs.bvh_depth < 1 ? 1 : fs.bvh_depth;   // one entry per level; flatten / load refuse trees deeper than RTC_BVH_MAX_DEPTH: nothing is clamped here
+#endif
     v.n_media = fs.n_media;
     v.leaf_kinds = fs.leaf_kinds;
     v.tex_kinds = 0; for (const auto &t : fs.textures) v.tex_kinds |= 1 << t.type;
@@ -275,6 +289,15 @@ int rtc_scene_dump_bvh(const rtc_scene *scene, void *nodes16, int node_cap, void
     if (leaves16) std::memcpy(leaves16, fs.bleaves.data(), nl * sizeof(BLeaf));
     if (prim_of_slot) std::memcpy(prim_of_slot, fs.leaf_prims.data(), nl * sizeof(int));
     return (int)fs.bleaves.size();
+}
+
+int rtc_scene_dump_bvh4(const rtc_scene *scene, void *nodes32, int node_cap, int *stack_entries) {
+    if (!scene) return fail(RTC_ERR_ARG, "rtc_scene_dump_bvh4: null scene");
+    const FlatScene &fs = scene->flat;
+    static_assert(sizeof(BvhNode4) == 128, "table layout");
+    if (nodes32) std::memcpy(nodes32, fs.nodes4.data(), std::min((size_t)(node_cap > 0 ? node_cap : 0), fs.nodes4.size()) * sizeof(BvhNode4));
+    if (stack_entries) *stack_entries = fs.bvh_stack;
+    return (int)fs.nodes4.size();
 }
 
 // Every compute entry point: the scene has device tables, and they live on the calling thread's current device (a kernel

@@ -25,6 +25,7 @@ template <int OP> __global__ void __launch_bounds__(256) k(float *out, float see
             if (OP == 7) u[i] = (u[i] ^ (u[i] >> 7)) + 0x9E3779B9u;                               // cheap int
             if (OP == 8) a[i] = a[i] > 1.0f ? a[i] * 0.5f : a[i] + 0.25f;                         // cmp + cndmask-ish
             if (OP == 9) { asm volatile("v_mul_u32_u24 %0, %0, %1" : "+v"(u[i]) : "v"(u[(i + 1) & 7])); }
+            if (OP == 10) { asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(seed), "v"(a[(i + 1) & 7])); }   // one FMA per lane: never packed
         }
     }
     float s = 0; for (int i = 0; i < 8; i++) s += a[i] + (float)u[i] + (float)(w[i] & 0xffff);
@@ -50,9 +51,11 @@ template <int OP> int run(const char *name, int instr_per_iter_per_chain) {
 int main(int argc, char **argv) {
     // `valu_rates calib`: the pure v_fma_f32 loop alone, 64x longer, for reading SQ_INSTS_VALU / SQ_ACTIVE_INST_VALU / GRBM_GUI_ACTIVE
     // under rocprofv3 --pmc: the loop that must read "VALU issue utilisation 1.0" 
-    if (argc > 1 && argv[1][0] == 'c') { g_repeat = 64; run<0>("v_fma_f32 (calibration)", 1); run<0>("v_fma_f32 (calibration)", 1); return 0; }
+    // (OP 0 is compiled to v_pk_fma_f32 -- two FMAs per lane and instruction -- by hipcc's SLP pass; OP 10 is the scalar v_fma_f32
+    // the production kernels, built with -fno-slp-vectorize, are made of)
+    if (argc > 1 && argv[1][0] == 'c') { g_repeat = 64; run<10>("v_fma_f32 (asm, calibration)", 1); run<0>("fmaf x8 (v_pk_fma_f32, calibration)", 1); return 0; }
     run<0>("v_fma_f32", 1); run<1>("v_rcp_f32", 1); run<2>("v_sqrt_f32", 1); run<3>("v_sin_f32", 1);
     run<4>("v_mad_u64_u32", 1); run<5>("v_mul_lo_u32(+add)", 2); run<6>("v_mul_hi_u32(+xor)", 2); run<7>("xor/shift/add (3)", 3);
-    run<8>("cmp+cndmask+mul+add", 4); run<9>("v_mul_u32_u24", 1);
+    run<8>("cmp+cndmask+mul+add", 4); run<9>("v_mul_u32_u24", 1); run<10>("v_fma_f32 (asm, unpacked)", 1);
     return 0;
 }

@@ -42,11 +42,55 @@ ALGO_FLOP_PER_RAY = 218.6
 PEAK_FP32_VALU_TFLOPS = 157.3     # MI355X_MICROARCH.md: 256 CU x 4 SIMD x 32 lanes x 2 (FMA) x 2.4 GHz
 ALGO_HBM_BYTES_PER_PIXEL = 32     # float4 accumulator read + write once per launch
 PEAK_L2_GBS = 34500.0             # MI355X_MICROARCH.md: 8 x 4 MiB L2, ~34.5 TB/s aggregate (HBM3E: 8 TB/s)
-# BVH scenes (wavefront kernels): measured traversal steps per ray (probe builds RT_EXP=3/4) ->
-# algorithmic bytes per ray = (node steps + leaf steps) x 64 B (node and traversal leaf are both 64 B; steps measured with
-# the RT_EXP=3/4 probe builds) + 166 B of path-slot state per bounce (extend 48 R + 9 W, shade 61 R + 48 W)
-SCENE_BYTES = {"final": (10.4 + 3.3) * 64 + 166, "final_earth": (10.0 + 2.7) * 64 + 166, "book1": (9.5 + 2.4) * 64 + 166,
-               "million": (23.6 + 2.7) * 64 + 166}
+# BVH scenes (wavefront kernels).  Per ray, measured with the RT_EXP=3/4 probe builds: node steps and leaf
+# steps of the production two-child tree.
+#   bytes/ray = (node steps + leaf steps) x 64 B (a node and a traversal leaf are both 64 B) + 166 B of path-slot state per
+#               bounce (extend 48 R + 9 W, shade 61 R + 48 W)
+#   FLOP/ray  = node steps x 30 (two aabb slab tests, aabb.c:33-63 at 15 each) + leaf steps x leaf test (sphere 26,
+#               hittable.c:406-429; rect 6; a box record's slab ~18: scene average) + everything that is not traversal, from
+#               the instrumented oracle run of tests/flop_model.py on the same scene (hit records, media, textures, materials,
+#               camera): final 128.1, final_earth 119.4, book1 32.8
+# Which roof: final / final_earth / book1 keep their trees (<= 285 KB) in L2 and are bound by VALU issue under divergence
+# (profiles/r02b: extend active-lane 0.23, wait 0.49) -> "valu"; the 1M-sphere tree (105 MB) is served by L2 + Infinity Cache
+# (TCC hit rate 0.55, wait 0.68) -> "l2", with the L2 requests counted by rocprofv3 beside the algorithmic bytes.
+SCENE_MODEL = {
+    "final":       dict(node_steps=10.4, leaf_steps=3.3, leaf_flop=22, other_flop=128.1, bound="valu"),
+    "final_earth": dict(node_steps=10.0, leaf_steps=2.7, leaf_flop=22, other_flop=119.4, bound="valu"),
+    "book1":       dict(node_steps=9.5, leaf_steps=2.4, leaf_flop=26, other_flop=32.8, bound="valu"),
+    "million":     dict(node_steps=23.6, leaf_steps=2.7, leaf_flop=26, other_flop=32.8, bound="l2"),
+}
+for _m in SCENE_MODEL.values():
+    _m["bytes_per_ray"] = (_m["node_steps"] + _m["leaf_steps"]) * 64 + 166
+    _m["flop_per_ray"] = _m["node_steps"] * 30 + _m["leaf_steps"] * _m["leaf_flop"] + _m["other_flop"]
+SCENE_BYTES = {k: v["bytes_per_ray"] for k, v in SCENE_MODEL.items()}
+WORKLOADS = {"final": "02_AdvancedTracer final scene", "final_earth": "02_AdvancedTracer final scene + earth-map globe",
+             "book1": "01_BasicTracer Book-1 random spheres", "million": "synthetic 1,000,004-sphere scene"}
+
+
+def scene_roofline(scene, rays_per_launch, k_ms):
+    """roofline object of a BVH scene: FP32 VALU roof where the kernels are issue bound, aggregate L2 where they wait for node fetches."""
+    m = SCENE_MODEL[scene]
+    common = {"kernel": "k_wf_extend + k_wf_shade", "kernel_ms": k_ms, "rays_per_launch": rays_per_launch,
+              "algorithmic_flop_per_ray": m["flop_per_ray"], "algorithmic_bytes_per_ray": m["bytes_per_ray"],
+              "node_steps_per_ray": m["node_steps"], "leaf_steps_per_ray": m["leaf_steps"]}
+    if m["bound"] == "valu":
+        tf = m["flop_per_ray"] * rays_per_launch / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
+        return dict(common, bound="valu", achieved=tf, peak=PEAK_FP32_VALU_TFLOPS, unit="TFLOP/s", frac=tf / PEAK_FP32_VALU_TFLOPS, traffic=None)
+    gbs = m["bytes_per_ray"] * rays_per_launch / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+    l2 = measured_l2_requests(scene)
+    return dict(common, bound="l2", achieved=gbs, peak=PEAK_L2_GBS, unit="GB/s", frac=gbs / PEAK_L2_GBS, traffic=None, l2_counters=l2)
+
+
+def measured_l2_requests(scene):
+    """TCC_HIT + TCC_MISS of k_wf_extend per launch from the committed rocprofv3 pass of this scene (profiles/r02b), or None."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r02b", scene, "summary.json")) as f:
+            s = json.load(f)
+        p = s["pmc_per_launch"]
+        return {"profile": "r02b/" + scene, "kernel": s.get("kernel"), "tcc_hit_per_launch": p["TCC_HIT_sum"], "tcc_miss_per_launch": p["TCC_MISS_sum"],
+                "hit_rate": p["TCC_HIT_sum"] / (p["TCC_HIT_sum"] + p["TCC_MISS_sum"]), "kernel_ms": s.get("avg_ms")}
+    except (OSError, KeyError, ValueError, ZeroDivisionError):
+        return None
 
 
 def measured_traffic():
@@ -93,6 +137,25 @@ def cpu_baseline(budget_s=15.0):
     return out
 
 
+def other_config(scene, W, H, spp, dev):
+    """One BASELINE configuration outside the headline: scene build, one warm-up render, one measured render (HBM-resident)."""
+    t0 = time.perf_counter()
+    sc, cam, view = ra.build_named_scene(scene, arg=1000 if scene == "million" else 0, aspect=W / H)
+    build_s = time.perf_counter() - t0
+    acc = rdist.new_accum(H, W, dev)
+    st = None
+    for rep in range(2):
+        acc.zero_()
+        stream = rdist.render_into(sc, cam, ra.Settings(W, H, spp, view.max_depth, view.integrator, seed=rep), acc)
+        torch.cuda.synchronize()
+        st = sc.stats(stream)
+    out = {"workload": f"{WORKLOADS[scene]}, {W}x{H}, {spp} spp, depth {view.max_depth}", "scene_build_s": round(build_s, 3),
+           "ms": st["kernel_ms"], "msamples_per_s": st["samples"] / st["kernel_ms"] * 1e-3, "mrays_per_s": st["rays"] / st["kernel_ms"] * 1e-3,
+           "rays_per_sample": st["rays"] / st["samples"], "roofline": scene_roofline(scene, st["rays"], st["kernel_ms"])}
+    sc.close()
+    return out
+
+
 def main():
     global WIDTH, HEIGHT
     ap = argparse.ArgumentParser()
@@ -103,6 +166,7 @@ def main():
     ap.add_argument("--width", type=int, default=WIDTH, help="image width (BASELINE config 4: --width 3840 --height 2160 --spp 2048 on 8 GPUs)")
     ap.add_argument("--height", type=int, default=HEIGHT)
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--no-other", action="store_true", help="skip the once-each renders of BASELINE configs 3 and 5 behind the timed region")
     ap.add_argument("--scene", default="cornell", choices=sorted(SCENE_BYTES) + ["cornell"],
                     help="cornell = BASELINE config 2/4 (default, the headline line); final / final_earth = config 3; million = config 5; "
                          "book1 = config 1 on the GPU.  The CPU leg and the committed PMC traffic only exist for cornell")
@@ -179,8 +243,7 @@ def main():
         achieved = ALGO_FLOP_PER_RAY * rays_per_launch / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
         traffic = measured_traffic() if (cornell, WIDTH, HEIGHT, a.spp) == (True, 1920, 1080, SPP_PER_GPU) else None   # the committed PMC passes ran the default workload
         workload = ("03_FullTracer Cornell box (setupScene), mixture-PDF light/glass-sphere importance sampling" if cornell else
-                    {"final": "02_AdvancedTracer final scene", "final_earth": "02_AdvancedTracer final scene + earth-map globe",
-                     "book1": "01_BasicTracer Book-1 random spheres", "million": "synthetic 1,000,004-sphere scene"}[a.scene])
+                    WORKLOADS[a.scene])
         line = {
             "metric": "Msamples/sec (whole node) @1080p Cornell box" if cornell else f"Msamples/sec (whole node), scene {a.scene}",
             "value": samples_all / elapsed / 1e6, "unit": "Msamples/s",
@@ -198,12 +261,11 @@ def main():
                          "algorithmic_hbm_bytes_per_launch": ALGO_HBM_BYTES_PER_PIXEL * WIDTH * HEIGHT},
         }
         if not cornell:
-            # BVH scenes: the tree (1M spheres: 56 MB) is served by the L2s and the 256 MB Infinity Cache, not by HBM (measured
-            # HBM reads: 44 MB per extend launch), so the algorithmic fetch bytes are priced against the aggregate L2 bandwidth
-            gbs = SCENE_BYTES[a.scene] * rays_per_launch / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
-            line["roofline"] = {"bound": "l2", "achieved": gbs, "peak": PEAK_L2_GBS, "unit": "GB/s", "frac": gbs / PEAK_L2_GBS, "traffic": None,
-                                "kernel": "k_wf_extend + k_wf_shade", "kernel_ms": k_ms, "rays_per_launch": rays_per_launch,
-                                "algorithmic_bytes_per_ray": SCENE_BYTES[a.scene]}
+            line["roofline"] = scene_roofline(a.scene, rays_per_launch, k_ms)
+        if world == 1 and cornell and not a.no_other:
+            # BASELINE configs 3 and 5 once each, AFTER the timed region (the headline value above is untouched): so that the
+            # driver's record carries the BVH scenes too
+            line["other_configs"] = [other_config("final", 1024, 1024, 256, dev), other_config("million", 1920, 1080, 64, dev)]
         if world == 1 and not a.no_cpu and cornell:
             line.update(cpu_baseline())
             line["speedup_vs_cpu_baseline"] = line["value"] / line["cpu_baseline"]["value"]

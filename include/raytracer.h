@@ -140,7 +140,7 @@ enum { RT_SCENE_SIMPLE = 0, RT_SCENE_CORNELL = 1, RT_SCENE_FINAL = 2, RT_SCENE_B
 #define RT_SCENES_TYPES 1
 hittable_list *rt_scene_build(int id, int arg, hittable_list *lights, rt_scene_view *view);
 /* image file of RT_SCENE_EARTH / RT_SCENE_FINAL_EARTH (the reference hard-codes "images/earthmap.jpg", 02 main.c:159);
- * JPEG or binary PPM; default "tests/golden/earthmap_512.ppm" relative to the working directory */
+ * JPEG or binary PPM; default "tests/golden/earthmap.jpg" (the reference's own 1024x512 asset) relative to the working directory */
 void rt_scene_set_image_path(const char *path);
 
 /* ---- image output: 8-bit RGB rows top-to-bottom -> PNG.  flip_vertically=1 reproduces

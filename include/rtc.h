@@ -136,6 +136,17 @@ int rtc_first_hit_f32(const rtc_scene *scene, const double *rays7, size_t n, dou
 int rtc_render_device(const rtc_scene *scene, const camera *cam, const rtc_settings *settings,
                       float *accum_rgba_device, void *stream);
 int rtc_render(const rtc_scene *scene, const camera *cam, const rtc_settings *settings, float *accum_rgba_host);
+/* Multi-GPU from a C host (BASELINE config 4; the reference's only fan-out is the OpenMP loop over 16 row chunks of ONE process,
+ * 03 main.c:132-138).  rtc_scene_clone_to_device uploads a copy of a scene's flattened tables to another HIP device (the
+ * flattening and BVH build are not repeated); NULL + rtc_last_error() on failure.  rtc_render_multi renders samples
+ * [sample_begin, sample_end) of every pixel split over the n handles -- one host thread per handle, each on its handle's
+ * device, contiguous disjoint shards, earlier handles take the remainder -- brings the accumulators to scenes[0]'s device with
+ * peer copies (xGMI), adds them there in handle order and ADDS the sum to accum_rgba_host (W*H float4).  Handles must be
+ * distinct; two handles may live on one device (that is how a one-GPU box tests the path).  Float sums are reassociated
+ * across shards: 1e-5 relative against the one-device render, sample counts exact. */
+rtc_scene *rtc_scene_clone_to_device(const rtc_scene *scene, int device);
+int rtc_render_multi(const rtc_scene *const *scenes, int n_scenes, const camera *cam, const rtc_settings *settings, float *accum_rgba_host);
+
 /* NO COUNTERPART IN THE REFERENCE (its CPU loop allocates freely: two mallocs per diffuse bounce, pdf.c:21-25).  For callers
  * that cannot allocate -- code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc: rtc_render_device
  * with the same arguments and the same kernels, but its scratch (ray counters, tile costs and order, per-chunk partial sums)

@@ -53,7 +53,7 @@ class RtcStats(C.Structure):
 
 SCENES = dict(simple=0, cornell=1, final=2, book1=3, cornell02=4, cornell_smoke=5, two_spheres=6, two_perlin=7,
               simple_light=8, book2_random=9, million=10, earth=11, final_earth=12, box_field=13, box_field_smoke=14)
-EARTHMAP = os.path.join(os.path.dirname(_HERE), "tests", "golden", "earthmap_512.ppm")
+EARTHMAP = os.path.join(os.path.dirname(_HERE), "tests", "golden", "earthmap.jpg")   # the reference's images/earthmap.jpg, 1024x512
 
 _P = C.c_void_p
 _dp = C.POINTER(C.c_double)
@@ -70,7 +70,7 @@ hittable_rotate_init hittable_constant_medium_init hittable_constant_medium_init
 hittable_free camera_new camera_free camera_fields camera_get_ray write_color ray_color material_free texture_free rt_scene_build rt_scene_set_image_path rt_write_png rt_write_ppm_p3""".split()
 RTC_SYMBOLS = """rtc_init rtc_last_error rtc_device_name rtc_scene_build rtc_scene_flatten_only rtc_scene_save rtc_scene_load rtc_scene_load_host rtc_scene_free rtc_scene_num_prims
 rtc_scene_dump_leaves rtc_scene_bvh_info rtc_scene_dump_bvh rtc_scene_dump_bvh4 rtc_first_hit_f64 rtc_first_hit_f32 rtc_primary_first_hit_f64 rtc_render_device rtc_render_device_noalloc rtc_render rtc_render_stats
-rtc_tonemap_u8_device rtc_tonemap_u8 rtc_ray_colors rtc_kat make_scene free_scene render_scene render_scene_accumulate""".split()
+rtc_tonemap_u8_device rtc_tonemap_u8 rtc_ray_colors rtc_kat rtc_scene_clone_to_device rtc_render_multi make_scene free_scene render_scene render_scene_accumulate""".split()
 
 
 def lib():
@@ -153,6 +153,10 @@ def lib():
     L.rtc_render_stats.argtypes = [_P, _P, C.POINTER(RtcStats)]
     L.rtc_tonemap_u8_device.argtypes = [_P, C.c_int, C.c_int, _P, _P]
     L.rtc_tonemap_u8.argtypes = [_P, C.c_int, C.c_int, _P]
+    if hasattr(L, "rtc_render_multi"):
+        L.rtc_scene_clone_to_device.restype = _P
+        L.rtc_scene_clone_to_device.argtypes = [_P, C.c_int]
+        L.rtc_render_multi.argtypes = [C.POINTER(_P), C.c_int, _P, C.POINTER(RtcSettings), _P]
     L.rtc_ray_colors.argtypes = [_P, _dp, C.c_size_t, C.POINTER(RtcSettings), _dp]
     L.rtc_kat.argtypes = [_P, C.c_int, _dp, C.c_size_t, _dp]
     L.write_color.argtypes = [_P, C.POINTER(Vec3), C.c_int, C.c_int]

@@ -284,12 +284,12 @@ struct BvhTrav {
     unsigned n_steps = 0;                                        // probe: node (3) or leaf (4) steps of this ray
 #endif
 };
-RT_DEV void bvh_begin(BvhTrav &s, const RayT<float> &r, float tmax, int src_slot) {
+RT_DEV void bvh_begin(BvhTrav &s, const RayT<float> &r, float tmax, int src_slot, int root) {
     // 1/d clamped to +-1e30: a zero component must not turn lo * inv - o * inv into inf - inf (slab_f32)
     s.r = r; s.inv = mk3<float>(fminf(fmaxf(__builtin_amdgcn_rcpf(r.d.x), -1e30f), 1e30f), fminf(fmaxf(__builtin_amdgcn_rcpf(r.d.y), -1e30f), 1e30f),
                                 fminf(fmaxf(__builtin_amdgcn_rcpf(r.d.z), -1e30f), 1e30f));
     s.noi = mk3<float>(-r.o.x * s.inv.x, -r.o.y * s.inv.y, -r.o.z * s.inv.z);
-    s.h.t = tmax; s.h.prim = -1; s.h.slot = -1; s.cur = 0; s.src_slot = src_slot;
+    s.h.t = tmax; s.h.prim = -1; s.h.slot = -1; s.cur = root; s.src_slot = src_slot;
 }
 // RT_BVH4 = 1: A/B build that traverses the four-child tree (rtc_tables.h BvhNode4) instead of the two-child one.  Measured
 // SLOWER on every BVH scene (final +21 %, 1M spheres +13 %, book1 +4 %, profiles/r02b): a step tests four boxes and orders
@@ -376,7 +376,7 @@ RT_DEV void bvh_leaf_step(const SceneT<float> &sc, const BLeaf &lf, BvhTrav &s, 
 // trips per trip.
 template <int KINDS = RTC_KIND_ALL, typename Stack, typename MediumFn>
 RT_DEV HitS bvh_closest_hit(const SceneT<float> &sc, const RayT<float> &r, float tmin, float tmax, Stack &stack, MediumFn &&medium, int src_slot = -1) {
-    BvhTrav s; bvh_begin(s, r, tmax, src_slot);
+    BvhTrav s; bvh_begin(s, r, tmax, src_slot, sc.bvh_root);
 #if !RT_BVH4
     while (s.cur != RTC_BVH_EMPTY) {
         const bool node = s.cur >= 0;

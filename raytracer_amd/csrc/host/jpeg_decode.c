@@ -1,17 +1,22 @@
 /*
  * jpeg_decode.c -- baseline JPEG decoder for image textures (product code, host).
  *
- * The reference loads images/earthmap.jpg through stb_image (03_FullTracer/texture.c:63-70).  stb is third-party code
- * that lives only inside the reference tree and is not vendored here; this is an independent implementation of the
- * published format (ITU-T T.81 baseline sequential DCT, Huffman coding, 8-bit samples; JFIF YCbCr):
- *   - 1 or 3 components, sampling factors 1 or 2, restart intervals;
- *   - exact separable inverse DCT in double precision, rounded once (stb uses a 12-bit integer IDCT: samples may differ
- *     by one level);
- *   - chroma upsampling by the usual triangle filter (3/4, 1/4) for 2x subsampled planes;
- *   - JFIF colour conversion in 20-bit fixed point.
- * Progressive (SOF2), arithmetic-coded, 12-bit and CMYK files are refused (return 0), like any file that is cut short.
- * tests/test_host_api.py pins it to pixels decoded by the reference's own loader (tests/golden/earthmap_decode.npz):
- * |difference| <= 3 of 255 on every sample, 99.8 % of the samples within 1.
+ * The reference loads images/earthmap.jpg through stb_image v2.26 (03_FullTracer/texture.c:63-70 -> stbi_load(..., 3)).  stb is
+ * third-party code that lives only inside the reference tree and is not vendored here; this is a decoder of the published
+ * format (ITU-T T.81 baseline sequential DCT, Huffman coding, 8-bit samples; JFIF YCbCr) whose three lossy stages are
+ * restated from the algorithms stb_image documents, operation for operation, so that the TEXELS ARE BIT-IDENTICAL to the
+ * reference's (a nearest-texel lookup, texture.c:136-152, shows every level of difference):
+ *   - inverse DCT: the IJG "islow" integer IDCT (jidctint) with 12-bit constants, column pass kept at 2 extra bits, a DC-only
+ *     column shortcut, row pass rounded at 17 bits with the +128 level shift folded in (stb_image.h:2352-2450);
+ *   - chroma upsampling, row by row: 2x horizontally (3/4, 1/4), 2x vertically (3/4, 1/4), both (9/16 .. 1/16, rounded once),
+ *     nearest for anything else; the far row alternates as in stb's ystep logic (stb_image.h:3364-3426, 3794-3836);
+ *   - YCbCr -> RGB in 20-bit fixed point with 12-bit coefficients, the Cb term of G truncated to 16 bits before the sum
+ *     (stb_image.h:3556-3582); component ids "RGB" (or Adobe transform 0 without JFIF) mean no conversion.
+ *   - 1 or 3 components, sampling factors 1 or 2, restart intervals.
+ * Progressive (SOF2), arithmetic-coded, 12-bit and CMYK files are refused (return 0), like any file that is cut short
+ * (stb decodes progressive files; no reference scene has one).
+ * tests/test_host_api.py: equal to the reference's own stbi_load output on every sample of images/earthmap.jpg and of
+ * 4:2:0 / 4:2:2 / 4:4:0 / grey / restart-interval files (tests/golden/jpeg_cases.npz, made by the compiled reference).
  */
 #include <math.h>
 #include <stdlib.h>
@@ -65,51 +70,76 @@ static int huff_decode(bitreader *br, const huff_table *t) {
 }
 static int extend(int v, int n) { return n && v < (1 << (n - 1)) ? v - (1 << n) + 1 : v; }
 
-static double g_cos[8][8];
-static void idct_init(void) {
-    static int done = 0;
-    if (done) return;
-    for (int x = 0; x < 8; x++)
-        for (int u = 0; u < 8; u++) g_cos[x][u] = (u == 0 ? sqrt(0.5) : 1.0) * 0.5 * cos((2 * x + 1) * u * 3.14159265358979323846 / 16.0);
-    done = 1;
-}
-static void idct_block(const int *coef, unsigned char *out, int stride) {
-    double tmp[64];
-    for (int v = 0; v < 8; v++)                                       /* rows of coefficients -> spatial x */
-        for (int x = 0; x < 8; x++) { double s = 0; for (int u = 0; u < 8; u++) s += g_cos[x][u] * coef[8 * v + u]; tmp[8 * v + x] = s; }
-    for (int x = 0; x < 8; x++)
-        for (int y = 0; y < 8; y++) {
-            double s = 0; for (int v = 0; v < 8; v++) s += g_cos[y][v] * tmp[8 * v + x];
-            int q = (int)floor(s + 128.5);
-            out[y * stride + x] = (unsigned char)(q < 0 ? 0 : (q > 255 ? 255 : q));
-        }
-}
-
-/* sample of a component plane at full-resolution pixel (x, y), triangle filter for 2x subsampled directions */
-static int plane_sample(const component *c, int hmax, int vmax, int x, int y) {
-    const int sx = hmax / c->h, sy = vmax / c->v;
-    if (sx == 1 && sy == 1) return c->plane[y * c->stride + x];
-    int x0 = x, x1 = x, wx = 0, y0 = y, y1 = y, wy = 0;                /* weights in quarters for the second tap */
-    if (sx == 2) { x0 = x >> 1; x1 = (x & 1) ? x0 + 1 : x0 - 1; wx = 1; } else if (sx > 2) x0 = x1 = x / sx;
-    if (sy == 2) { y0 = y >> 1; y1 = (y & 1) ? y0 + 1 : y0 - 1; wy = 1; } else if (sy > 2) y0 = y1 = y / sy;
-    x1 = x1 < 0 ? 0 : (x1 >= c->w ? c->w - 1 : x1);
-    y1 = y1 < 0 ? 0 : (y1 >= c->hgt ? c->hgt - 1 : y1);
-    const unsigned char *p = c->plane;
-    const int a = p[y0 * c->stride + x0], b = p[y0 * c->stride + x1], d = p[y1 * c->stride + x0], e = p[y1 * c->stride + x1];
-    const int near_w = wx ? 3 : 4, far_w = wx ? 1 : 0, near_h = wy ? 3 : 4, far_h = wy ? 1 : 0;
-    const int top = near_w * a + far_w * b, bot = near_w * d + far_w * e;           /* x 4 */
-    return (near_h * top + far_h * bot + 8) >> 4;
+/* One 8-point pass of the IJG islow IDCT on s[0], s[st], ..., s[7 st]; constants = round(c * 4096).  Outputs the even part
+ * x[0..3] and the odd part t[0..3] scaled by 4096: the caller adds its rounding bias to x and forms x[k] +- t[3 - k]. */
+static void idct_1d(const int *s, int st, int x[4], int t[4]) {
+    int p2 = s[2 * st], p3 = s[6 * st];
+    int p1 = (p2 + p3) * 2217;
+    const int e2 = p1 + p3 * -7567, e3 = p1 + p2 * 3135;
+    p2 = s[0]; p3 = s[4 * st];
+    const int e0 = (p2 + p3) * 4096, e1 = (p2 - p3) * 4096;
+    x[0] = e0 + e3; x[3] = e0 - e3; x[1] = e1 + e2; x[2] = e1 - e2;
+    int t0 = s[7 * st], t1 = s[5 * st], t2 = s[3 * st], t3 = s[st];
+    p3 = t0 + t2; int p4 = t1 + t3; p1 = t0 + t3; p2 = t1 + t2;
+    const int p5 = (p3 + p4) * 4816;
+    t0 *= 1223; t1 *= 8410; t2 *= 12586; t3 *= 6149;
+    p1 = p5 + p1 * -3685; p2 = p5 + p2 * -10497; p3 *= -8034; p4 *= -1597;
+    t[3] = t3 + p1 + p4; t[2] = t2 + p2 + p3; t[1] = t1 + p2 + p4; t[0] = t0 + p1 + p3;
 }
 static unsigned char clamp8(int v) { return (unsigned char)(v < 0 ? 0 : (v > 255 ? 255 : v)); }
+static void idct_block(const short *coef, unsigned char *out, int stride) {
+    int val[64];
+    for (int c = 0; c < 8; c++) {                                      /* columns; 2 extra bits kept */
+        const short *d = coef + c; int *v = val + c;
+        if (d[8] == 0 && d[16] == 0 && d[24] == 0 && d[32] == 0 && d[40] == 0 && d[48] == 0 && d[56] == 0) {
+            const int dc = d[0] * 4;
+            for (int k = 0; k < 8; k++) v[8 * k] = dc;
+            continue;
+        }
+        int in[8], x[4], t[4];
+        for (int k = 0; k < 8; k++) in[k] = d[8 * k];
+        idct_1d(in, 1, x, t);
+        for (int k = 0; k < 4; k++) { x[k] += 512; v[8 * k] = (x[k] + t[3 - k]) >> 10; v[8 * (7 - k)] = (x[k] - t[3 - k]) >> 10; }
+    }
+    for (int r = 0; r < 8; r++) {                                      /* rows: 12 + 2 + 3 bits to drop, level shift +128 folded in */
+        int x[4], t[4];
+        idct_1d(val + 8 * r, 1, x, t);
+        unsigned char *o = out + (size_t)r * stride;
+        for (int k = 0; k < 4; k++) { x[k] += 65536 + (128 << 17); o[k] = clamp8((x[k] + t[3 - k]) >> 17); o[7 - k] = clamp8((x[k] - t[3 - k]) >> 17); }
+    }
+}
 
+/* One output row of a component at full width: `near` is the component row the output row lies in, `far` its neighbour on the
+ * side the output row leans to (the same row at the image's top and bottom edge).  w = samples of the component in a row. */
+static const unsigned char *upsample_row(unsigned char *out, const unsigned char *near, const unsigned char *far, int w, int hs, int vs) {
+    if (hs == 1 && vs == 1) return near;
+    if (hs == 1 && vs == 2) { for (int i = 0; i < w; i++) out[i] = (unsigned char)((3 * near[i] + far[i] + 2) >> 2); return out; }
+    if (hs == 2 && vs == 1) {
+        if (w == 1) { out[0] = out[1] = near[0]; return out; }
+        out[0] = near[0]; out[1] = (unsigned char)((near[0] * 3 + near[1] + 2) >> 2);
+        int i;
+        for (i = 1; i < w - 1; i++) { const int n = 3 * near[i] + 2; out[2 * i] = (unsigned char)((n + near[i - 1]) >> 2); out[2 * i + 1] = (unsigned char)((n + near[i + 1]) >> 2); }
+        out[2 * i] = (unsigned char)((near[w - 2] * 3 + near[w - 1] + 2) >> 2); out[2 * i + 1] = near[w - 1];
+        return out;
+    }
+    if (hs == 2 && vs == 2) {
+        if (w == 1) { out[0] = out[1] = (unsigned char)((3 * near[0] + far[0] + 2) >> 2); return out; }
+        int t1 = 3 * near[0] + far[0];
+        out[0] = (unsigned char)((t1 + 2) >> 2);
+        for (int i = 1; i < w; i++) { const int t0 = t1; t1 = 3 * near[i] + far[i]; out[2 * i - 1] = (unsigned char)((3 * t0 + t1 + 8) >> 4); out[2 * i] = (unsigned char)((3 * t1 + t0 + 8) >> 4); }
+        out[2 * w - 1] = (unsigned char)((t1 + 2) >> 2);
+        return out;
+    }
+    for (int i = 0; i < w; i++) for (int j = 0; j < hs; j++) out[i * hs + j] = near[i];   /* other factors: nearest */
+    return out;
+}
 /* Returns 1 and a malloc'ed RGB8 image (rows top to bottom) on success, 0 on any malformed or unsupported file. */
 int rt_jpeg_decode(const unsigned char *data, size_t n, int *width, int *height, unsigned char **rgb_out) {
     if (!data || n < 4 || data[0] != 0xFF || data[1] != 0xD8) return 0;
-    idct_init();
     unsigned short qt[4][64]; int qt_present[4] = {0, 0, 0, 0};
     huff_table *dc = (huff_table *)calloc(4, sizeof(huff_table)), *ac = (huff_table *)calloc(4, sizeof(huff_table));
     component comp[3]; memset(comp, 0, sizeof comp);
-    int ncomp = 0, W = 0, H = 0, hmax = 1, vmax = 1, restart = 0, ok = 0, have_frame = 0;
+    int ncomp = 0, W = 0, H = 0, hmax = 1, vmax = 1, restart = 0, ok = 0, have_frame = 0, jfif = 0, adobe_transform = -1, is_rgb = 0;
     size_t pos = 2;
     unsigned char *rgb = NULL;
     if (!dc || !ac) goto done;
@@ -158,6 +188,10 @@ int rt_jpeg_decode(const unsigned char *data, size_t n, int *width, int *height,
                 memcpy(t->vals, seg + i, (size_t)total); i += (size_t)total;
                 huff_build(t);
             }
+        } else if (m == 0xE0) {                                         /* APP0: "JFIF\0" */
+            if (sl >= 5 && memcmp(seg, "JFIF", 5) == 0) jfif = 1;
+        } else if (m == 0xEE) {                                         /* APP14: "Adobe\0", colour transform in its 12th byte */
+            if (sl >= 12 && memcmp(seg, "Adobe", 6) == 0) adobe_transform = seg[11];
         } else if (m == 0xDD) {                                         /* DRI */
             if (sl < 2) goto done;
             restart = (seg[0] << 8) | seg[1];
@@ -170,6 +204,7 @@ int rt_jpeg_decode(const unsigned char *data, size_t n, int *width, int *height,
                 comp[c].td = seg[2 + 2 * s] >> 4; comp[c].ta = seg[2 + 2 * s] & 15;
                 if (comp[c].td > 3 || comp[c].ta > 3 || !dc[comp[c].td].present || !ac[comp[c].ta].present || !qt_present[comp[c].tq]) goto done;
             }
+            is_rgb = ncomp == 3 && ((comp[0].id == 'R' && comp[1].id == 'G' && comp[2].id == 'B') || (adobe_transform == 0 && !jfif));   /* stb_image.h:3778 */
             const int mcu_w = 8 * hmax, mcu_h = 8 * vmax, mcus_x = (W + mcu_w - 1) / mcu_w, mcus_y = (H + mcu_h - 1) / mcu_h;
             for (int c = 0; c < ncomp; c++) {
                 comp[c].stride = mcus_x * 8 * comp[c].h; comp[c].w = (W * comp[c].h + hmax - 1) / hmax; comp[c].hgt = (H * comp[c].v + vmax - 1) / vmax;
@@ -192,11 +227,11 @@ int rt_jpeg_decode(const unsigned char *data, size_t n, int *width, int *height,
                     for (int c = 0; c < ncomp; c++)
                         for (int by = 0; by < comp[c].v; by++)
                             for (int bx = 0; bx < comp[c].h; bx++) {
-                                int coef[64]; memset(coef, 0, sizeof coef);
+                                short coef[64]; memset(coef, 0, sizeof coef);                /* 16-bit like stb's: the product wraps there too */
                                 int t = huff_decode(&br, dc + comp[c].td);
                                 if (t < 0 || t > 11) goto done;
                                 comp[c].pred += extend(get_bits(&br, t), t);
-                                coef[0] = comp[c].pred * qt[comp[c].tq][0];
+                                coef[0] = (short)(comp[c].pred * qt[comp[c].tq][0]);
                                 for (int k = 1; k < 64;) {
                                     int rs = huff_decode(&br, ac + comp[c].ta);
                                     if (rs < 0) goto done;
@@ -204,7 +239,7 @@ int rt_jpeg_decode(const unsigned char *data, size_t n, int *width, int *height,
                                     if (s == 0) { if (r != 15) break; k += 16; continue; }
                                     k += r;
                                     if (k > 63) goto done;
-                                    coef[kZigzag[k]] = extend(get_bits(&br, s), s) * qt[comp[c].tq][kZigzag[k]];
+                                    coef[kZigzag[k]] = (short)(extend(get_bits(&br, s), s) * qt[comp[c].tq][kZigzag[k]]);
                                     k++;
                                 }
                                 unsigned char *dst = comp[c].plane + (size_t)((my * comp[c].v + by) * 8) * comp[c].stride + (size_t)(mx * comp[c].h + bx) * 8;
@@ -215,17 +250,38 @@ int rt_jpeg_decode(const unsigned char *data, size_t n, int *width, int *height,
                 }
             rgb = (unsigned char *)malloc((size_t)W * H * 3);
             if (!rgb) goto done;
-            for (int y = 0; y < H; y++)
-                for (int x = 0; x < W; x++) {
-                    unsigned char *o = rgb + ((size_t)y * W + x) * 3;
-                    const int Y = plane_sample(&comp[0], hmax, vmax, x, y);
-                    if (ncomp == 1) { o[0] = o[1] = o[2] = (unsigned char)Y; continue; }
-                    const int cb = plane_sample(&comp[1], hmax, vmax, x, y) - 128, cr = plane_sample(&comp[2], hmax, vmax, x, y) - 128;
-                    const int yf = (Y << 20) + (1 << 19);               /* JFIF: R = Y + 1.402 Cr, G = Y - 0.34414 Cb - 0.71414 Cr, B = Y + 1.772 Cb */
-                    o[0] = clamp8((yf + cr * 1470208) >> 20);           /* round(1.402   * 2^20) at 12-bit precision: 5743 << 8 */
-                    o[1] = clamp8((yf - cr * 748800 - cb * 360960) >> 20);   /* 2925 << 8, 1410 << 8 */
-                    o[2] = clamp8((yf + cb * 1858048) >> 20);           /* 7258 << 8 */
+            {   /* row by row: upsample every component to full width, then convert (stb_image.h:3794-3850) */
+                unsigned char *line[3] = {NULL, NULL, NULL};
+                const unsigned char *row0[3], *row1[3]; int ystep[3], ypos[3], hs[3], vs[3], wl[3];
+                int alloc_ok = 1;
+                for (int c = 0; c < ncomp; c++) {
+                    line[c] = (unsigned char *)malloc((size_t)W + 3 + 8);
+                    if (!line[c]) alloc_ok = 0;
+                    hs[c] = hmax / comp[c].h; vs[c] = vmax / comp[c].v; ystep[c] = vs[c] >> 1; ypos[c] = 0; wl[c] = (W + hs[c] - 1) / hs[c];
+                    row0[c] = row1[c] = comp[c].plane;
                 }
+                for (int y = 0; y < H && alloc_ok; y++) {
+                    const unsigned char *cur[3] = {NULL, NULL, NULL};
+                    for (int c = 0; c < ncomp; c++) {
+                        const int bot = ystep[c] >= (vs[c] >> 1);
+                        cur[c] = upsample_row(line[c], bot ? row1[c] : row0[c], bot ? row0[c] : row1[c], wl[c], hs[c], vs[c]);
+                        if (++ystep[c] >= vs[c]) { ystep[c] = 0; row0[c] = row1[c]; if (++ypos[c] < comp[c].hgt) row1[c] += comp[c].stride; }
+                    }
+                    unsigned char *o = rgb + (size_t)y * W * 3;
+                    for (int x = 0; x < W; x++, o += 3) {
+                        if (ncomp == 1) { o[0] = o[1] = o[2] = cur[0][x]; continue; }
+                        if (is_rgb) { o[0] = cur[0][x]; o[1] = cur[1][x]; o[2] = cur[2][x]; continue; }
+                        const int yf = (cur[0][x] << 20) + (1 << 19), cb = cur[1][x] - 128, cr = cur[2][x] - 128;
+                        /* JFIF: R = Y + 1.402 Cr, G = Y - 0.71414 Cr - 0.34414 Cb, B = Y + 1.772 Cb; coefficients round(c * 4096) << 8;
+                         * the Cb term of G loses its low 16 bits before it is added (stb's SIMD-compatible form) */
+                        o[0] = clamp8((yf + cr * 1470208) >> 20);
+                        o[1] = clamp8((int)(yf + cr * -748800 + (int)((unsigned)(cb * -360960) & 0xffff0000u)) >> 20);
+                        o[2] = clamp8((yf + cb * 1858048) >> 20);
+                    }
+                }
+                for (int c = 0; c < 3; c++) free(line[c]);
+                if (!alloc_ok) goto done;
+            }
             *width = W; *height = H; *rgb_out = rgb; rgb = NULL; ok = 1;
             goto done;
         }

@@ -93,7 +93,7 @@ static hittable_list *scene_cornell(hittable_list *lights, rt_scene_view *v) {
 
 /* Image asset of the earth scenes.  The reference names "images/earthmap.jpg" relative to its working directory
  * (02 main.c:159); here the path is settable, and the default is the fixture that travels with this repository. */
-static char g_rt_image_path[1024] = "tests/golden/earthmap_512.ppm";
+static char g_rt_image_path[1024] = "tests/golden/earthmap.jpg";
 void rt_scene_set_image_path(const char *path) { if (path) { strncpy(g_rt_image_path, path, sizeof g_rt_image_path - 1); g_rt_image_path[sizeof g_rt_image_path - 1] = 0; } }
 
 /* 02 main.c:230-289 -- Book-2 final scene.  rand() order: 400 box heights, BVH nodes,

@@ -136,8 +136,22 @@ __global__ void __launch_bounds__(256) k_tonemap_u8(const float4 *__restrict__ a
     }
 }
 
+// dst += src over n float4 (rtc_render_multi: the accumulators of the other devices, added on the root in device order)
+__global__ void __launch_bounds__(256) k_accum_add(float4 *__restrict__ dst, const float4 *__restrict__ src, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float4 a = dst[i]; const float4 b = src[i];
+    a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    dst[i] = a;
+}
+
 }  // namespace
 
+hipError_t launch_accum_add(float4 *dst, const float4 *src, size_t n, hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_accum_add, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, dst, src, n);
+    return hipGetLastError();
+}
 hipError_t launch_pathtrace_mega(const SceneT<float> &sc, const CameraT<float> &cam, const RenderParams &p,
                                  float4 *accum, unsigned long long *ray_counter, hipStream_t stream) {
     if (p.n_tiles <= 0 || p.s_end <= p.s_begin) return hipSuccess;

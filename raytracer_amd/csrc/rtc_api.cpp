@@ -11,6 +11,7 @@
 #include <map>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "kernels.h"
@@ -92,7 +93,9 @@ template <typename R> hipError_t upload_tables(const FlatScene &fs, DeviceTables
     v.bleaves = (const BLeaf *)dt.bleaves.p; v.leaf_shade = (const SmallShade *)dt.leaf_shade.p;
     v.ref_steps = (const RefStep *)dt.ref_steps.p; v.ref_boxes = (const double *)dt.ref_boxes.p;
     v.n_ref_steps = with_ref_steps ? (int)fs.ref_steps.size() : 0;
+    v.bvh_root = (fs.nodes.size() == 1 && fs.nodes[0].child1 == RTC_BVH_EMPTY) ? fs.nodes[0].child0 : 0;
 #if RT_BVH4
+    v.bvh_root = 0;   // the four-child step tests child != RTC_BVH_EMPTY itself
     v.bvh_stack = fs.bvh_stack < 1 ? 1 : fs.bvh_stack;
 #else
     v.bvh_stack = fs.bvh_depth < 1 ? 1 : fs.bvh_depth;   // one entry per level; flatten / load refuse trees deeper than RTC_BVH_MAX_DEPTH: nothing is clamped here
@@ -222,15 +225,19 @@ static rtc_scene *upload_scene(rtc_scene *s, const char *who) {
     return s;
 }
 
+// Scenes of more leaves than this are traversed through the BVH, smaller ones by the brute-force / small-scene kernels.
+// RTC_BVH_THRESHOLD is a development knob (tests build a BVH over one or two primitives with it), like RTC_BUILD_THREADS.
+static int bvh_threshold() { const char *e = std::getenv("RTC_BVH_THRESHOLD"); return e ? std::max(0, std::atoi(e)) : 64; }
+
 rtc_scene *rtc_scene_build(const hittable_list *world, const hittable_list *lights, const color *background, double time0, double time1) {
     rtc_scene *s = new rtc_scene();
     // brute force up to 64 leaves: the uniform loop runs out of SGPR-fed scalar loads; above that the linear BVH wins
-    if (!flatten_scene(world, lights, background, time0, time1, 64, s->flat)) { g_error = "flatten: " + s->flat.error; delete s; return nullptr; }
+    if (!flatten_scene(world, lights, background, time0, time1, bvh_threshold(), s->flat)) { g_error = "flatten: " + s->flat.error; delete s; return nullptr; }
     return upload_scene(s, "rtc_scene_build");
 }
 rtc_scene *rtc_scene_flatten_only(const hittable_list *world, const hittable_list *lights, const color *background, double time0, double time1) {
     rtc_scene *s = new rtc_scene();
-    if (!flatten_scene(world, lights, background, time0, time1, 64, s->flat)) { g_error = "flatten: " + s->flat.error; delete s; return nullptr; }
+    if (!flatten_scene(world, lights, background, time0, time1, bvh_threshold(), s->flat)) { g_error = "flatten: " + s->flat.error; delete s; return nullptr; }
     return s;   // device == -1: every compute entry point refuses this handle
 }
 int rtc_scene_save(const rtc_scene *scene, const char *path) {
@@ -711,6 +718,79 @@ color ray_color(ray *r, color *background, hittable_list *world, hittable_list *
     if (rtc_ray_colors(cached, ray7, 1, &st, rgb) != RTC_OK) { std::printf("!! ray_color: %s\n", rtc_last_error()); return black; }
     const color out = {rgb[0], rgb[1], rgb[2]};
     return out;
+}
+
+// A copy of a scene's tables on another device (the flattening is not repeated).
+rtc_scene *rtc_scene_clone_to_device(const rtc_scene *scene, int device) {
+    if (!scene) { g_error = "rtc_scene_clone_to_device: null scene"; g_error_literal = nullptr; return nullptr; }
+    int n = 0, prev = -1;
+    if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) { g_error = "rtc_scene_clone_to_device: no such HIP device"; g_error_literal = nullptr; return nullptr; }
+    (void)hipGetDevice(&prev);
+    if (hipSetDevice(device) != hipSuccess) { g_error = "rtc_scene_clone_to_device: hipSetDevice failed"; g_error_literal = nullptr; return nullptr; }
+    rtc_scene *s = new rtc_scene();
+    s->flat = scene->flat;
+    s = upload_scene(s, "rtc_scene_clone_to_device");
+    if (prev >= 0) (void)hipSetDevice(prev);
+    return s;
+}
+
+// BASELINE config 4 from a C host: one host thread per scene handle (= per device), disjoint sample shards, the accumulators
+// brought to the first handle's device by peer copies and added there in handle order, one download.
+int rtc_render_multi(const rtc_scene *const *scenes, int n_scenes, const camera *cam, const rtc_settings *st, float *accum_host) {
+    if (!scenes || n_scenes < 1 || !cam || !accum_host) return fail(RTC_ERR_ARG, "rtc_render_multi: null argument");
+    if (n_scenes > 64) return fail(RTC_ERR_ARG, "rtc_render_multi: at most 64 scene handles");
+    int rc = check_settings(st); if (rc) return rc;
+    for (int i = 0; i < n_scenes; i++) if (!scenes[i] || scenes[i]->device < 0) return fail(RTC_ERR_DEVICE, "rtc_render_multi: scene handle " + std::to_string(i) + " has no device tables");
+    for (int i = 0; i < n_scenes; i++) for (int j = 0; j < i; j++) if (scenes[i] == scenes[j]) return fail(RTC_ERR_ARG, "rtc_render_multi: the same scene handle twice (clone it: rtc_scene_clone_to_device)");
+    const size_t n_pix = (size_t)st->width * st->height, bytes = n_pix * 4 * sizeof(float);
+    const int spp = st->sample_end - st->sample_begin, q = spp / n_scenes, r = spp % n_scenes;
+    int prev = -1; (void)hipGetDevice(&prev);
+    std::vector<void *> acc((size_t)n_scenes, nullptr);
+    std::vector<int> status((size_t)n_scenes, RTC_OK);
+    std::vector<std::string> message((size_t)n_scenes);
+    std::vector<std::thread> threads;
+    for (int i = 0; i < n_scenes; i++)
+        threads.emplace_back([&, i]() {
+            // shard i: contiguous, disjoint, exhaustive -- earlier handles take the remainder (raytracer_amd/dist.py shard_samples)
+            rtc_settings mine = *st;
+            mine.sample_begin = st->sample_begin + i * q + std::min(i, r);
+            mine.sample_end = mine.sample_begin + q + (i < r ? 1 : 0);
+            auto bad = [&](const char *what) { status[(size_t)i] = RTC_ERR_DEVICE; message[(size_t)i] = std::string("rtc_render_multi, handle ") + std::to_string(i) + ": " + what; };
+            if (hipSetDevice(scenes[i]->device) != hipSuccess) return bad("hipSetDevice failed");
+            if (hipMalloc(&acc[(size_t)i], bytes) != hipSuccess) { acc[(size_t)i] = nullptr; status[(size_t)i] = RTC_ERR_NOMEM; message[(size_t)i] = "rtc_render_multi: accumulator does not fit in device memory"; return; }
+            if (hipMemset(acc[(size_t)i], 0, bytes) != hipSuccess) return bad("hipMemset failed");
+            if (mine.sample_end > mine.sample_begin) {
+                const int rc_i = rtc_render_device(scenes[i], cam, &mine, (float *)acc[(size_t)i], nullptr);
+                if (rc_i != RTC_OK) { status[(size_t)i] = rc_i; message[(size_t)i] = rtc_last_error(); return; }
+            }
+            if (hipDeviceSynchronize() != hipSuccess) return bad("the render failed on the device");
+        });
+    for (auto &t : threads) t.join();
+    int first_bad = -1;
+    for (int i = 0; i < n_scenes && first_bad < 0; i++) if (status[(size_t)i] != RTC_OK) first_bad = i;
+    hipError_t e = hipSuccess;
+    const int root = scenes[0]->device;
+    void *stage = nullptr;
+    if (first_bad < 0) {
+        e = hipSetDevice(root);
+        if (e == hipSuccess && n_scenes > 1) e = hipMalloc(&stage, bytes);
+        for (int i = 1; i < n_scenes && e == hipSuccess; i++) {          // fixed order: the sum does not depend on which device finished first
+            e = hipMemcpyPeer(stage, root, acc[(size_t)i], scenes[i]->device, bytes);   // xGMI when peers can see each other, staged through the host otherwise
+            if (e == hipSuccess) e = launch_accum_add((float4 *)acc[0], (const float4 *)stage, n_pix, nullptr);
+            if (e == hipSuccess) e = hipDeviceSynchronize();
+        }
+        if (e == hipSuccess) {
+            std::vector<float> sum(n_pix * 4);
+            e = hipMemcpy(sum.data(), acc[0], bytes, hipMemcpyDeviceToHost);
+            if (e == hipSuccess) for (size_t k = 0; k < sum.size(); k++) accum_host[k] += sum[k];   // the call ADDS, like rtc_render
+        }
+    }
+    for (int i = 0; i < n_scenes; i++) if (acc[(size_t)i]) { (void)hipSetDevice(scenes[i]->device); (void)hipFree(acc[(size_t)i]); }
+    if (stage) { (void)hipSetDevice(root); (void)hipFree(stage); }
+    if (prev >= 0) (void)hipSetDevice(prev);
+    if (first_bad >= 0) return fail(status[(size_t)first_bad], message[(size_t)first_bad]);
+    if (e != hipSuccess) return fail(RTC_ERR_DEVICE, std::string("rtc_render_multi: reduce failed: ") + hipGetErrorString(e));
+    return RTC_OK;
 }
 
 int rtc_tonemap_u8_device(const float *accum_dev, int width, int height, unsigned char *rgb_dev, void *stream) {

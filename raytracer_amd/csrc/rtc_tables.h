@@ -87,6 +87,7 @@ template <typename R> struct SceneT {
     const BvhNode *nodes;    const BvhNode4 *nodes4;  const int *leaf_prims; int n_nodes;   // n_nodes == 0: brute-force loop over prims; nodes4: RT_BVH4 builds only
     const BLeaf *bleaves;                                          // FP32 production BVH only (NULL in the FP64 tables)
     const struct SmallShade *leaf_shade;                           // per leaf slot: everything shading needs of a resolved leaf, one 48-byte read
+    int bvh_root;            // where a traversal starts: node 0, or the leaf run itself when the whole scene is one leaf (its node's second child is RTC_BVH_EMPTY and its box is never tested)
     int bvh_stack;           // entries the traversal stack needs: the levels of the binary tree (RT_BVH4: max over paths of the sum of (children - 1))
     const RefStep *ref_steps; const double *ref_boxes; int n_ref_steps;   // FP64 check path; boxes = min xyz, max xyz
     int n_media;             // media among prims (stochastic hits)

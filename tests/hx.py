@@ -18,7 +18,24 @@ ORACLE_SO = os.path.join(ROOT, "oracle", "_build", "liboracle.so")
 REF03_SO = os.path.join(ROOT, "oracle", "_ref", "libref03.so")
 REF02_SO = os.path.join(ROOT, "oracle", "_ref", "libref02.so")
 REF01_SO = os.path.join(ROOT, "oracle", "_ref", "libref01.so")
-EARTHMAP = os.path.join(ROOT, "tests", "golden", "earthmap_512.ppm")   # image asset of the earth scenes (make_earth_fixture.py)
+EARTHMAP = os.path.join(ROOT, "tests", "golden", "earthmap.jpg")   # image asset of the earth scenes: the reference's own images/earthmap.jpg (1024x512)
+
+
+def earthmap_for(is_oracle):
+    """The compiled reference decodes the JPEG itself (stb_image).  The oracle reads binary PPM only (oracle/cpu_ref.c:190), so it
+    gets the reference's full decode of that file (tests/golden/earthmap_decode.npz, make_jpeg_cases.py) written out as a PPM."""
+    if not is_oracle:
+        return EARTHMAP
+    import tempfile
+    path = os.path.join(tempfile.gettempdir(), f"rtc_earthmap_1024_{os.getuid()}.ppm")
+    if not os.path.exists(path):
+        rgb = np.load(os.path.join(ROOT, "tests", "golden", "earthmap_decode.npz"))["rgb"]
+        tmp = path + f".{os.getpid()}"
+        with open(tmp, "wb") as f:
+            f.write(b"P6\n%d %d\n255\n" % (rgb.shape[1], rgb.shape[0]))
+            f.write(np.ascontiguousarray(rgb).tobytes())
+        os.replace(tmp, path)
+    return path
 
 SCENE = dict(simple=0, cornell=1, final=2, book1=3, cornell02=4, cornell_smoke=5, two_spheres=6,
              two_perlin=7, simple_light=8, book2_random=9, million=10, earth=11, final_earth=12, box_field=13, box_field_smoke=14,
@@ -45,7 +62,7 @@ class Harness:
         self.lib = C.CDLL(path)
         self.lib.hx_stage.restype = C.c_int
         self.is_oracle = hasattr(self.lib, "hx_oracle_render")
-        self.lib.hx_set_image_path(EARTHMAP.encode())
+        self.lib.hx_set_image_path(earthmap_for(self.is_oracle).encode())
 
     # -- scene -----------------------------------------------------------------------------
     def stage(self):

@@ -82,3 +82,35 @@ def test_two_ranks_on_one_gpu_equal_one_process(gpu, tmp_path):
         assert int(got[name + "_rays"][0]) == st["rays"]               # the same paths were traced, split in two
         d = np.abs(got[name + "_u8"].astype(int) - gpu.tonemap_u8(acc).astype(int))
         assert d.max() <= 1 and (d > 0).mean() < 1e-3                  # bytes: equal except where a sum sits on a rounding boundary
+
+
+def test_c_abi_multi_device_render_equals_one_device(gpu):
+    """rtc_render_multi (include/rtc.h): one host thread per scene handle, sample shards, peer-copy reduce on the root.  A one-GPU
+    box runs it with two and three handles on cuda:0 (rtc_scene_clone_to_device): sums equal the single render within float
+    reassociation, sample counts exact, the call adds to what the host buffer held; the same handle twice is refused."""
+    import ctypes as C
+    L = gpu.lib()
+    for name, W, H, spp in (("cornell", 240, 135, 70), ("book1", 160, 90, 20)):
+        sc, cam, view = gpu.build_named_scene(name, aspect=W / H)
+        clones = []
+        try:
+            st = gpu.Settings(W, H, 0, view.max_depth, view.integrator, seed=5, sample_begin=3, sample_end=3 + spp)
+            want, _ = sc.render(cam, st)
+            for n in (2, 3):
+                while len(clones) < n - 1:
+                    h = L.rtc_scene_clone_to_device(sc.handle, 0)
+                    assert h, L.rtc_last_error()
+                    clones.append(h)
+                handles = (C.c_void_p * n)(sc.handle, *clones[:n - 1])
+                acc = np.full((H, W, 4), 1.0, dtype=np.float32)
+                rc = L.rtc_render_multi(handles, n, cam.handle, C.byref(st.c), acc.ctypes.data)
+                assert rc == 0, L.rtc_last_error()
+                assert (acc[..., 3] == spp + 1).all()
+                assert np.allclose(acc[..., :3] - 1.0, want[..., :3], rtol=1e-5, atol=2e-5 * spp)
+            dup = (C.c_void_p * 2)(sc.handle, sc.handle)
+            assert L.rtc_render_multi(dup, 2, cam.handle, C.byref(st.c), acc.ctypes.data) != 0 and b"twice" in L.rtc_last_error()
+            assert L.rtc_scene_clone_to_device(sc.handle, 99) is None
+        finally:
+            for h in clones:
+                L.rtc_scene_free(h)
+            sc.close()

@@ -185,3 +185,48 @@ def test_production_fp32_traversal_agrees_with_fp64(gpu, name, spread):
         assert ((p32 >= 0) != (p64 >= 0)).mean() <= 0.002
     finally:
         sc.close()
+
+
+@pytest.mark.parametrize("n_spheres", [1, 2, 3])
+def test_bvh_over_one_leaf(gpu, monkeypatch, n_spheres):
+    """A BVH whose root is a single leaf run (one or two primitives: its node's second child is RTC_BVH_EMPTY and must never be
+    entered or shadow the first) and the smallest real tree (three).  RTC_BVH_THRESHOLD=0 makes flatten build a BVH for any
+    scene.  Rays through the unit cube around the origin -- where an unguarded empty child's box would sit -- must find the
+    spheres behind it; FP32 traversal against the FP64 closest-hit kernel."""
+    monkeypatch.setenv("RTC_BVH_THRESHOLD", "0")
+    L = gpu.lib()
+    v3 = gpu.api.v3
+    world = L.hittable_list_new(4)
+    mat = L.material_lambertian_new_from_color(v3((0.5, 0.5, 0.5)))
+    centres = [(5.0, 0.0, 0.0), (0.0, 6.0, 0.5), (-4.0, -4.0, 3.0)][:n_spheres]
+    for c in centres:
+        L.hittable_sphere_new(world, v3(c), 0.75, mat)
+    sc = gpu.Scene(world, None, (0.5, 0.7, 1.0))
+    try:
+        info = sc.bvh_info()
+        assert info["nodes"] == 1 and info["leaf_slots"] == n_spheres
+        rng = np.random.default_rng(n_spheres)
+        rays = []
+        for c in centres:                                           # from beyond the origin, through the unit cube, at each sphere
+            c = np.array(c)
+            o = -c / np.linalg.norm(c) * 5.0 + rng.uniform(-0.3, 0.3, size=(500, 3))
+            target = c + rng.uniform(-0.6, 0.6, size=(500, 3))
+            rays.append(np.concatenate([o, target - o, np.zeros((500, 1))], axis=1))
+        o = rng.uniform(-0.9, 0.9, size=(1000, 3))                  # from inside the cube, any direction
+        rays.append(np.concatenate([o, rng.normal(size=(1000, 3)), np.zeros((1000, 1))], axis=1))
+        rays = np.concatenate(rays).astype(np.float32).astype(np.float64)
+        p64, t64 = sc.first_hit(rays)
+        p32, t32 = sc.first_hit_f32(rays)
+        assert (p64 >= 0).sum() > 200 * n_spheres and (p64 < 0).sum() > 300
+        assert ((p32 >= 0) != (p64 >= 0)).mean() <= 0.004           # grazing rays only
+        both = (p32 >= 0) & (p64 >= 0)
+        assert np.array_equal(p32[both], p64[both])
+        assert np.abs(t32[both] - t64[both]).max() <= 2e-4 * np.maximum(1.0, t64[both]).max()
+        # the render takes the same traversal: a 16 x 16 image from behind the origin sees the first sphere
+        cam = gpu.Camera(tuple(-np.array(centres[0])), centres[0], (0, 0, 1), 20.0, 1.0, 0.0, 10.0)
+        acc, st = sc.render(cam, gpu.Settings(16, 16, 64, 8, 2, seed=3, kernel=2))
+        centre_px = acc[7:9, 7:9, :3].mean(axis=(0, 1)) / 64
+        sky = acc[0, 0, :3] / 64
+        assert st["kernel_used"] == 2 and np.abs(centre_px - sky).max() > 0.05
+    finally:
+        sc.close()

@@ -9,7 +9,7 @@ OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd /tmp
-BENCH="python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu"
+BENCH="python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu --no-other"
 run() { # name, rocprof args...
     local name=$1; shift
     timeout -s KILL 180 rocprofv3 "$@" --output-format csv -d "$OUT/$name" -o "$name" -- $BENCH > "$OUT/$name.log" 2>&1

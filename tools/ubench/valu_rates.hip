@@ -25,6 +25,16 @@ template <int OP> __global__ void __launch_bounds__(256) k(float *out, float see
             if (OP == 7) u[i] = (u[i] ^ (u[i] >> 7)) + 0x9E3779B9u;                               // cheap int
             if (OP == 8) a[i] = a[i] > 1.0f ? a[i] * 0.5f : a[i] + 0.25f;                         // cmp + cndmask-ish
             if (OP == 9) { asm volatile("v_mul_u32_u24 %0, %0, %1" : "+v"(u[i]) : "v"(u[(i + 1) & 7])); }
+            if (OP == 11) { asm volatile("v_fmac_f32_e32 %0, %1, %2" : "+v"(a[i]) : "v"(seed), "v"(a[(i + 1) & 7])); }      // VOP2, 4-byte encoding
+            if (OP == 12) { asm volatile("v_mul_f32_e32 %0, %1, %0" : "+v"(a[i]) : "v"(seed)); }
+            if (OP == 13) { asm volatile("v_mul_f32_e64 %0, %1, %0" : "+v"(a[i]) : "v"(seed)); }                              // same op, 8-byte encoding
+            if (OP == 14) { asm volatile("v_mov_b32_e32 %0, %1" : "=v"(a[i]) : "v"(a[(i + 1) & 7])); }
+            if (OP == 15) { asm volatile("v_cndmask_b32_e32 %0, %0, %1, vcc" : "+v"(a[i]) : "v"(a[(i + 1) & 7]) : ); }
+            if (OP == 16) { asm volatile("v_max_f32_e32 %0, %1, %0" : "+v"(a[i]) : "v"(seed)); }
+            if (OP == 17) { asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(a[i]) : "v"(seed)); }                              // VOP3, no cross-chain operand
+            if (OP == 18) { asm volatile("v_xor_b32_e32 %0, %1, %0" : "+v"(u[i]) : "v"(u[(i + 1) & 7])); }
+            if (OP == 19) { asm volatile("v_add_f32_e32 %0, %1, %0" : "+v"(a[i]) : "v"(seed)); }
+            if (OP == 20) { asm volatile("v_and_or_b32 %0, %0, %1, %1" : "+v"(u[i]) : "v"(u[(i + 1) & 7])); }                 // VOP3 integer
             if (OP == 10) { asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(seed), "v"(a[(i + 1) & 7])); }   // one FMA per lane: never packed
         }
     }
@@ -54,6 +64,13 @@ int main(int argc, char **argv) {
     // (OP 0 is compiled to v_pk_fma_f32 -- two FMAs per lane and instruction -- by hipcc's SLP pass; OP 10 is the scalar v_fma_f32
     // the production kernels, built with -fno-slp-vectorize, are made of)
     if (argc > 1 && argv[1][0] == 'c') { g_repeat = 64; run<10>("v_fma_f32 (asm, calibration)", 1); run<0>("fmaf x8 (v_pk_fma_f32, calibration)", 1); return 0; }
+    if (argc > 1 && argv[1][0] == 'e') {   // encodings: VOP2 (4 bytes) against VOP3 (8 bytes), long runs
+        g_repeat = 16;
+        run<11>("v_fmac_f32_e32", 1); run<10>("v_fma_f32 (cross operand)", 1); run<17>("v_fma_f32 (own chain)", 1); run<12>("v_mul_f32_e32", 1); run<13>("v_mul_f32_e64", 1);
+        run<19>("v_add_f32_e32", 1); run<14>("v_mov_b32_e32", 1); run<15>("v_cndmask_b32_e32", 1); run<16>("v_max_f32_e32", 1); run<18>("v_xor_b32_e32", 1); run<20>("v_and_or_b32", 1);
+        run<4>("v_mad_u64_u32", 1); run<1>("v_rcp_f32", 1);
+        return 0;
+    }
     run<0>("v_fma_f32", 1); run<1>("v_rcp_f32", 1); run<2>("v_sqrt_f32", 1); run<3>("v_sin_f32", 1);
     run<4>("v_mad_u64_u32", 1); run<5>("v_mul_lo_u32(+add)", 2); run<6>("v_mul_hi_u32(+xor)", 2); run<7>("xor/shift/add (3)", 3);
     run<8>("cmp+cndmask+mul+add", 4); run<9>("v_mul_u32_u24", 1); run<10>("v_fma_f32 (asm, unpacked)", 1);

@@ -242,6 +242,12 @@ def main():
         rays_per_launch = rays_all / max(1, a.steps * world)
         achieved = ALGO_FLOP_PER_RAY * rays_per_launch / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
         traffic = measured_traffic() if (cornell, WIDTH, HEIGHT, a.spp) == (True, 1920, 1080, SPP_PER_GPU) else None   # the committed PMC passes ran the default workload
+        # the counters were read in another run: a kernel that has changed since (other name, or a launch more than 10 % off the
+        # profiled average) makes the committed figure stale -- then traffic is null and the source says why
+        if traffic:
+            name = "k_pathtrace_small<0, false, false>" if kernel_used[0] == 2 else "k_pathtrace_mega"
+            same = traffic.get("kernel") == name and traffic.get("kernel_ms") and abs(k_ms / traffic["kernel_ms"] - 1.0) <= 0.10
+            traffic["stale"] = not same
         workload = ("03_FullTracer Cornell box (setupScene), mixture-PDF light/glass-sphere importance sampling" if cornell else
                     WORKLOADS[a.scene])
         line = {
@@ -254,7 +260,7 @@ def main():
                        "sharding": f"samples/{world}", "collective": "reduce(sum) of float4[W*H] to rank 0" if world > 1 else "none"},
             "mrays_per_s": rays_all / elapsed / 1e6, "rays_per_sample": rays_all / samples_all,
             "roofline": {"bound": "valu", "achieved": achieved, "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP32_VALU_TFLOPS, "traffic": traffic["bytes"] if traffic else None,
+                         "frac": achieved / PEAK_FP32_VALU_TFLOPS, "traffic": traffic["bytes"] if traffic and not traffic["stale"] else None,
                          "traffic_source": traffic, "kernel": "k_pathtrace_small<0, false, false>" if kernel_used[0] == 2 else "k_pathtrace_mega",
                          "lane_fill": lane_fill[0], "kernel_ms": k_ms, "rays_per_launch": rays_per_launch,
                          "algorithmic_flop_per_ray": ALGO_FLOP_PER_RAY,

@@ -56,6 +56,8 @@ typedef struct rtc_stats {
 int rtc_init(void);
 const char *rtc_last_error(void);
 const char *rtc_device_name(void);
+/* HIP devices this process sees (0 without a usable runtime); rtc_scene_clone_to_device takes an index below it. */
+int rtc_device_count(void);
 
 /* Flatten the pointer graph (world list, lights list) into SoA device tables + linear BVH and upload them to the
  * current device.  Replaces what the reference does implicitly by keeping `world`/`lights` as pointer graphs that

@@ -68,7 +68,7 @@ hittable_list_index hittable_list_objects hittable_list_free hittable_lists_free
 hittable_rect_new hittable_box_new hittable_moving_sphere_new bvh_node_init hittable_translate_init
 hittable_rotate_init hittable_constant_medium_init hittable_constant_medium_init_c hittable_flip_face_init
 hittable_free camera_new camera_free camera_fields camera_get_ray write_color ray_color material_free texture_free rt_scene_build rt_scene_set_image_path rt_write_png rt_write_ppm_p3""".split()
-RTC_SYMBOLS = """rtc_init rtc_last_error rtc_device_name rtc_scene_build rtc_scene_flatten_only rtc_scene_save rtc_scene_load rtc_scene_load_host rtc_scene_free rtc_scene_num_prims
+RTC_SYMBOLS = """rtc_init rtc_last_error rtc_device_name rtc_device_count rtc_scene_build rtc_scene_flatten_only rtc_scene_save rtc_scene_load rtc_scene_load_host rtc_scene_free rtc_scene_num_prims
 rtc_scene_dump_leaves rtc_scene_bvh_info rtc_scene_dump_bvh rtc_scene_dump_bvh4 rtc_first_hit_f64 rtc_first_hit_f32 rtc_primary_first_hit_f64 rtc_render_device rtc_render_device_noalloc rtc_render rtc_render_stats
 rtc_tonemap_u8_device rtc_tonemap_u8 rtc_ray_colors rtc_kat rtc_scene_clone_to_device rtc_render_multi make_scene free_scene render_scene render_scene_accumulate""".split()
 

@@ -5,7 +5,8 @@
  * rtc_render on the GPU.  Extra flags: -S scene id (default 1 = Cornell box; the reference hard-codes the scene),
  * -a aspect (default W/H; the reference hard-codes 1.0), -d depth, -r seed, -A arg (scene size),
  * -W file (write the flattened scene, rtc_scene_save), -L file (render that file instead of flattening scene -S again;
- * -S still names the camera).
+ * -S still names the camera), -g N (render on N GPUs of this process: rtc_render_multi, sample shards, peer-copy reduce;
+ * 0 = all visible devices).
  */
 #include <stdio.h>
 #include <stdlib.h>
@@ -18,7 +19,7 @@ static double now_s(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &
 
 int main(int argc, char **argv) {
     const char *out = "output.png", *save_path = NULL, *load_path = NULL;
-    int W = 1024, H = -1, spp = 256, depth = -1, scene_id = RT_SCENE_CORNELL, arg = 0;
+    int W = 1024, H = -1, spp = 256, depth = -1, scene_id = RT_SCENE_CORNELL, arg = 0, n_gpus = 1;
     double aspect = -1; unsigned long long seed = 0;
     for (int i = 1; i < argc; i++) {
         if (argv[i][0] != '-') continue;
@@ -35,8 +36,9 @@ int main(int argc, char **argv) {
         case 'A': arg = atoi(argv[i + 1]); break;
         case 'W': save_path = argv[i + 1]; break;
         case 'L': load_path = argv[i + 1]; break;
+        case 'g': n_gpus = atoi(argv[i + 1]); break;
         default:
-            fprintf(stderr, "Usage: %s [-w width] [-h height] [-o outputFile] [-s sample_per_pixel] [-S scene] [-a aspect] [-d depth] [-r seed] [-A scene_arg] [-W scene_file_out] [-L scene_file_in]\n", argv[0]);
+            fprintf(stderr, "Usage: %s [-w width] [-h height] [-o outputFile] [-s sample_per_pixel] [-S scene] [-a aspect] [-d depth] [-r seed] [-A scene_arg] [-W scene_file_out] [-L scene_file_in] [-g gpus]\n", argv[0]);
             return EXIT_FAILURE;
         }
         i++;
@@ -62,8 +64,24 @@ int main(int argc, char **argv) {
     st.integrator = view.integrator; st.seed = seed; st.mixture_light_weight = 0.1;
     float *accum = (float *)calloc((size_t)W * H * 4, sizeof(float));
     unsigned char *pixels = (unsigned char *)malloc((size_t)W * H * 3);
-    if (rtc_render(scene, cam, &st, accum) != RTC_OK) { fprintf(stderr, "rtc_render: %s\n", rtc_last_error()); return EXIT_FAILURE; }
-    rtc_stats stats; rtc_render_stats(scene, NULL, &stats);
+    rtc_stats stats; memset(&stats, 0, sizeof stats);
+    enum { MAX_GPUS = 64 };
+    rtc_scene *scenes[MAX_GPUS] = {scene};
+    if (n_gpus <= 0) n_gpus = rtc_device_count();
+    if (n_gpus > MAX_GPUS || n_gpus > rtc_device_count()) { fprintf(stderr, "-g %d: this process sees %d device(s)\n", n_gpus, rtc_device_count()); return EXIT_FAILURE; }
+    if (n_gpus <= 1) {
+        if (rtc_render(scene, cam, &st, accum) != RTC_OK) { fprintf(stderr, "rtc_render: %s\n", rtc_last_error()); return EXIT_FAILURE; }
+        rtc_render_stats(scene, NULL, &stats);
+    } else {   /* one host thread and one copy of the tables per device; the flattening above is not repeated */
+        for (int d = 1; d < n_gpus; d++)
+            if (!(scenes[d] = rtc_scene_clone_to_device(scene, d))) { fprintf(stderr, "%s\n", rtc_last_error()); return EXIT_FAILURE; }
+        if (rtc_render_multi((const rtc_scene *const *)scenes, n_gpus, cam, &st, accum) != RTC_OK) { fprintf(stderr, "rtc_render_multi: %s\n", rtc_last_error()); return EXIT_FAILURE; }
+        for (int d = 0; d < n_gpus; d++) {   /* samples and rays add up; the devices ran side by side: the slowest one is the kernel time */
+            rtc_stats one; rtc_render_stats(scenes[d], NULL, &one);
+            stats.samples += one.samples; stats.rays += one.rays;
+            if (one.kernel_ms > stats.kernel_ms) stats.kernel_ms = one.kernel_ms;
+        }
+    }
     double t2 = now_s();
     if (rtc_tonemap_u8(accum, W, H, pixels) != RTC_OK) { fprintf(stderr, "rtc_tonemap_u8: %s\n", rtc_last_error()); return EXIT_FAILURE; }
     if (!rt_write_png(out, W, H, pixels, 1)) { fprintf(stderr, "could not write %s\n", out); return EXIT_FAILURE; }
@@ -73,6 +91,7 @@ int main(int argc, char **argv) {
     printf("kernel %.3f ms: %.1f Msamples/s, %.1f Mrays/s (%.2f rays/sample); png %.3f s -> %s\n", stats.kernel_ms,
            stats.samples / stats.kernel_ms * 1e-3, stats.rays / stats.kernel_ms * 1e-3, (double)stats.rays / (double)stats.samples, t3 - t2, out);
 
+    for (int d = 1; d < n_gpus; d++) rtc_scene_free(scenes[d]);
     rtc_scene_free(scene); free(accum); free(pixels);
     camera_free(cam);
     hittable_lists_free_all(); materials_free_all(); textures_free_all();

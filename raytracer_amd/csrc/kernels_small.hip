@@ -16,7 +16,7 @@
 //   * material / pdf dispatch is a switch on the record's type; lambertian sampling uses n + uniform-sphere (the same
 //     cosine law as onb.c + random_cosine_direction, without building the basis), the mixture pdf of pdf.c:119-121;
 //   * Philox4x32-7 on (pixel, sample, bounce); 2 blocks per path start are not needed here (no lens, no moving leaf).
-// 79 VGPRs -> 6 waves per SIMD (amdgpu_waves_per_eu), no spills; the SIMDs issue VALU instructions all the time, so what
+// 77 VGPRs -> 6 waves per SIMD (amdgpu_waves_per_eu), no VGPR spills, 6 KB of LDS (shading records + tile sums); the SIMDs issue VALU instructions all the time, so what
 // is left is the instruction count and the divergence of the material switch (DESIGN.md 3.1 has the cycle budget).
 #include <hip/hip_runtime.h>
 

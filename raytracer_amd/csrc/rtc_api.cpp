@@ -191,6 +191,7 @@ int rtc_init(void) {
     void *scratch_ptr = nullptr;               // the allocation-free entry point's scratch: resolve its address on this device now
     return noalloc_scratch(&scratch_ptr);
 }
+int rtc_device_count(void) { int n = 0; return hipGetDeviceCount(&n) == hipSuccess ? n : 0; }
 const char *rtc_device_name(void) {
     static thread_local char name[256];
     int dev = 0; hipDeviceProp_t prop;
@@ -612,6 +613,9 @@ int rtc_render_stats(const rtc_scene *scene_c, void *stream_v, rtc_stats *out) {
     auto it = s->streams.find(stream_v);
     if (it == s->streams.end() || !it->second.pending) return fail(RTC_ERR_ARG, "rtc_render_stats: no render was enqueued on this stream");
     StreamState &ss = it->second;
+    // the events and counters live on the scene's device, which need not be the caller's current one (rtc_render_multi)
+    struct OnDevice { int prev = -1; explicit OnDevice(int d) { if (hipGetDevice(&prev) != hipSuccess) prev = -1; if (d >= 0 && d != prev) (void)hipSetDevice(d); else prev = -1; }
+                      ~OnDevice() { if (prev >= 0) (void)hipSetDevice(prev); } } on_device(s->device);
     HIP_TRY(hipEventSynchronize(ss.ev1));
     float ms = 0; HIP_TRY(hipEventElapsedTime(&ms, ss.ev0, ss.ev1));
     unsigned long long cnt[4] = {0, 0, 0, 0};

@@ -41,6 +41,8 @@ SPP_PER_GPU = 256
 ALGO_FLOP_PER_RAY = 218.6
 PEAK_FP32_VALU_TFLOPS = 157.3     # MI355X_MICROARCH.md: 256 CU x 4 SIMD x 32 lanes x 2 (FMA) x 2.4 GHz
 ALGO_HBM_BYTES_PER_PIXEL = 32     # float4 accumulator read + write once per launch
+SMALL_KERNEL_NAME = "k_pathtrace_small<0, false, false, true>"   # 03 integrator, pinhole, not the cost probe, light pdfs fused into the intersection
+GATHER_PEAK_L2, GATHER_PEAK_BIG = 207e9, 57e9   # measured: profiles/r02d/gather_rates.txt
 PEAK_L2_GBS = 34500.0             # MI355X_MICROARCH.md: 8 x 4 MiB L2, ~34.5 TB/s aggregate (HBM3E: 8 TB/s)
 # BVH scenes (wavefront kernels).  Per ray, measured with the RT_EXP=3/4 probe builds: node steps and leaf
 # steps of the production two-child tree.
@@ -73,6 +75,11 @@ def scene_roofline(scene, rays_per_launch, k_ms):
     common = {"kernel": "k_wf_extend + k_wf_shade", "kernel_ms": k_ms, "rays_per_launch": rays_per_launch,
               "algorithmic_flop_per_ray": m["flop_per_ray"], "algorithmic_bytes_per_ray": m["bytes_per_ray"],
               "node_steps_per_ray": m["node_steps"], "leaf_steps_per_ray": m["leaf_steps"]}
+    # second wall of the traversal (profiles/r02d): 64-byte node / leaf records fetched at random; the gather loop of
+    # tools/ubench/gather_rates reaches 207 G records/s from an L2-resident table with full waves (57 G/s from a 100 MB table)
+    steps = (m["node_steps"] + m["leaf_steps"]) * rays_per_launch / (k_ms * 1e-3) if k_ms > 0 else 0.0
+    common["record_fetch"] = {"achieved_grecords_per_s": steps / 1e9, "gather_peak_l2_resident": GATHER_PEAK_L2 / 1e9,
+                              "gather_peak_100mb_table": GATHER_PEAK_BIG / 1e9, "frac_of_l2_resident_peak": steps / GATHER_PEAK_L2}
     if m["bound"] == "valu":
         tf = m["flop_per_ray"] * rays_per_launch / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
         return dict(common, bound="valu", achieved=tf, peak=PEAK_FP32_VALU_TFLOPS, unit="TFLOP/s", frac=tf / PEAK_FP32_VALU_TFLOPS, traffic=None)
@@ -245,7 +252,7 @@ def main():
         # the counters were read in another run: a kernel that has changed since (other name, or a launch more than 10 % off the
         # profiled average) makes the committed figure stale -- then traffic is null and the source says why
         if traffic:
-            name = "k_pathtrace_small<0, false, false>" if kernel_used[0] == 2 else "k_pathtrace_mega"
+            name = SMALL_KERNEL_NAME if kernel_used[0] == 2 else "k_pathtrace_mega"
             same = traffic.get("kernel") == name and traffic.get("kernel_ms") and abs(k_ms / traffic["kernel_ms"] - 1.0) <= 0.10
             traffic["stale"] = not same
         workload = ("03_FullTracer Cornell box (setupScene), mixture-PDF light/glass-sphere importance sampling" if cornell else
@@ -261,7 +268,7 @@ def main():
             "mrays_per_s": rays_all / elapsed / 1e6, "rays_per_sample": rays_all / samples_all,
             "roofline": {"bound": "valu", "achieved": achieved, "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP32_VALU_TFLOPS, "traffic": traffic["bytes"] if traffic and not traffic["stale"] else None,
-                         "traffic_source": traffic, "kernel": "k_pathtrace_small<0, false, false>" if kernel_used[0] == 2 else "k_pathtrace_mega",
+                         "traffic_source": traffic, "kernel": SMALL_KERNEL_NAME if kernel_used[0] == 2 else "k_pathtrace_mega",
                          "lane_fill": lane_fill[0], "kernel_ms": k_ms, "rays_per_launch": rays_per_launch,
                          "algorithmic_flop_per_ray": ALGO_FLOP_PER_RAY,
                          "algorithmic_hbm_bytes_per_launch": ALGO_HBM_BYTES_PER_PIXEL * WIDTH * HEIGHT},

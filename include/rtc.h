@@ -91,6 +91,10 @@ int  rtc_scene_dump_leaves(const rtc_scene *scene, double *out16, int cap);
  * hittable.c:163-215): out4 = inner nodes, leaf slots, levels, bytes of nodes + traversal leaves.  All 0 for a scene of
  * at most 64 leaves (brute-force loop). */
 int  rtc_scene_bvh_info(const rtc_scene *scene, long long *out4);
+/* The small-scene pack (scenes of <= 64 rect / sphere leaves): out8 = eligible, pairs, object spaces, slab-tested boxes, spheres,
+ * light pdfs fused into the intersection (every light-list entry is a world-space leaf of the pack), rects and spheres that
+ * carry a light's pdf.  Inspection only; no reference counterpart. */
+int  rtc_scene_small_info(const rtc_scene *scene, int *out8);
 /* The production BVH itself, for structural checks on a machine without a GPU: nodes16 = per inner node 16 words (float
  * lo0[3], int child0, float hi0[3], int count0, the same for child 1; child < 0 encodes a leaf run ~((first << 3) | (count-1))),
  * leaves16 = per leaf slot 16 words (15 floats of world-space geometry + meta), prim_of_slot = primitive id per leaf slot.

@@ -783,6 +783,49 @@ void box_items(const FlatScene &fs, const std::vector<Box> &prim_boxes, std::vec
 
 }  // namespace
 
+// Light-list entries that are leaves of the small-scene pack.  hittable_pdf_value (hittable.c:760-788) intersects the ray with the
+// light's own geometry; when that geometry is a world-space rect of a pair or a sphere of the pack, the bounce loop's intersection
+// of the NEXT ray computes the same t / roots anyway, so the kernel takes the pdf from there instead of a second loop over the
+// lights (kernels_small.hip).  Fused only if EVERY light with a pdf has such a leaf (a light that is a face of a SmallBox, sits
+// behind a wrapper or is not in the world at all keeps the explicit loop for the whole scene).  A light listed twice counts twice.
+void mark_small_lights(FlatScene &fs) {
+    auto clear = [&] { fs.small_fused = false; for (SmallPair &P : fs.small_pairs) P.f[12] = P.f[13] = 0.0f; for (SmallSphere &sp : fs.small_spheres) sp.pdf_k = 0.0f; };
+    clear();
+    if (!fs.small_ok || fs.lights.empty() || std::getenv("RTC_SMALL_NO_FUSE")) return;   // (development knob: the A/B partner of the fused path)
+    bool all = true;
+    for (const LightT<double> &l : fs.lights) {
+        if (l.kind == RTC_LIGHT_NONE) continue;                       // pdf 0 either way
+        bool found = false;
+        if (l.kind == RTC_LIGHT_SPHERE) {
+            for (SmallSphere &sp : fs.small_spheres)
+                if (!found && sp.c[0] == (float)l.d[0] && sp.c[1] == (float)l.d[1] && sp.c[2] == (float)l.d[2] && sp.r2 == (float)l.d[4]) {
+                    sp.pdf_k += (float)(1.0 / (2.0 * 3.14159265358979323846 * l.d[4])); found = true;
+                }
+        } else if (l.axis >= 0 && l.axis <= 2) {
+            // in-plane bounds in the pair's order: XY -> (x, y), XZ -> (x, z), YZ -> (y, z)
+            const float a0 = (float)(l.axis == RTC_AXIS_YZ ? l.d[2] : l.d[0]), a1 = (float)(l.axis == RTC_AXIS_YZ ? l.d[3] : l.d[1]);
+            const float b0 = (float)(l.axis == RTC_AXIS_XY ? l.d[2] : l.d[4]), b1 = (float)(l.axis == RTC_AXIS_XY ? l.d[3] : l.d[5]);
+            for (const SmallGroup &g : fs.small_groups) {
+                if (g.xform != 0 || found) continue;                 // world space only
+                const int first[3] = {g.first, g.first + g.n_xy, g.first + g.n_xy + g.n_xz}, count[3] = {g.n_xy, g.n_xz, g.n_yz};
+                for (int p = first[l.axis]; p < first[l.axis] + count[l.axis] && !found; p++) {
+                    SmallPair &P = fs.small_pairs[(size_t)p];
+                    for (int slot = 0; slot < 2 && !found; slot++) {
+                        int id; std::memcpy(&id, &P.f[10 + slot], sizeof id);
+                        if (id < 0) continue;
+                        if (P.f[slot] == (float)l.d[6] && P.f[2 + 4 * slot] == a0 && P.f[3 + 4 * slot] == b0 && P.f[4 + 4 * slot] == a1 && P.f[5 + 4 * slot] == b1) {
+                            P.f[12 + slot] += (float)l.d[7]; found = true;
+                        }
+                    }
+                }
+            }
+        }
+        all &= found;
+    }
+    if (!all) { clear(); return; }
+    fs.small_fused = true;
+}
+
 // Binary tree -> four-child tree.  A node4 starts with the two children of a binary node; while it has fewer than four, the
 // INNER child with the largest box surface is replaced by its own two children (the box most likely to be hit is opened
 // first: fewer, fuller steps).  Pre-order numbering (every child behind its parent, like the binary table).  The traversal
@@ -866,6 +909,7 @@ bool flatten_scene(const hittable_list *world, const hittable_list *lights, cons
         }
     lap("walk");
     build_small_pack(out);
+    mark_small_lights(out);
     if ((int)out.prims.size() > bvh_threshold) {
         std::vector<BuildItem> items; std::vector<Box> item_boxes;
         box_items(out, f.prim_boxes, items, item_boxes);

@@ -37,6 +37,9 @@ struct FlatScene {
     std::vector<SmallXform> small_xforms;
     bool small_ok = false, small_any_fuzz = false;
     int small_n_rects = 0;         // leaf ids: rects 0 .. small_n_rects-1, then the spheres
+    // Lights whose geometry IS a world-space leaf of the pack (mark_small_lights): the leaf's own intersection test then yields the
+    // light's pdf for the ray being traced (SmallPair f[12], f[13] = 1 / area per listing; SmallSphere pdf_k).  Derived, not stored.
+    bool small_fused = false;
     std::vector<int> wrap_depth;   // per prim: number of translate/rotate wrappers (for rtc_scene_dump_leaves)
     std::vector<int> flipped;      // per prim: parity of flip_face wrappers
     int n_media = 0;
@@ -49,6 +52,8 @@ struct FlatScene {
 // nodes -> nodes4 + bvh_stack (deterministic; also run after a scene file is loaded).  False + out.error when the tree needs
 // a deeper traversal stack than RTC_BVH_MAX_STACK.
 bool build_bvh4(FlatScene &out);
+// lights -> leaves of the small-scene pack (deterministic; also run after a scene file is loaded)
+void mark_small_lights(FlatScene &fs);
 
 // Walks world/lights once.  Primitive order = the reference's traversal order (list order, box sides in creation
 // order, BVH members in the order recorded by bvh_node_init).  Builds the BVH when the scene has more than

@@ -58,7 +58,11 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 // tbest starts at a large FINITE value: a t of +inf (dn == 0) then violates t - tbest, NaNs fail the compare.
 // A ray cannot hit the plane it leaves again: the leaf it starts on (src) is excluded -- in FP32 the start point is off the
 // plane by up to |k| 2^-24 (3e-5 at k = 555) and a grazing ray (|d_n| < 0.03) would meet it again at t >= tmin.
-RT_DEV void small_pair(const SmallPair &P, float on, float in, v2f oab, v2f dab, float tmin, int src, SmallHit &h) {
+// A rect that is also an entry of the lights list (P.f[12] / P.f[13] = 1 / area, flatten.cpp mark_small_lights; a wave-uniform
+// branch) adds its pdf for THIS ray to `pdf` on the way: hittable_pdf_value (hittable.c:772-788) is this very plane test with
+// tmin 1e-4 and no upper bound, value t^2 |1/d_n| / area for a unit direction (small_light_pdf_one below is the stand-alone form).
+template <bool PDF>
+RT_DEV void small_pair(const SmallPair &P, float on, float in, v2f oab, v2f dab, float tmin, int src, SmallHit &h, float &pdf) {
     const v2f k = {P.f[0], P.f[1]};
     const int id0 = __float_as_int(P.f[10]), id1 = __float_as_int(P.f[11]);
     const v2f t = (k - on) * in;
@@ -66,22 +70,27 @@ RT_DEV void small_pair(const SmallPair &P, float on, float in, v2f oab, v2f dab,
         const v2f p = oab + dab * t.x;
         const v2f lo = {P.f[2], P.f[3]}, hi = {P.f[4], P.f[5]};
         const v2f vl = lo - p, vh = p - hi;
-        const float viol = fmaxf(fmaxf(fmaxf(vl.x, vl.y), fmaxf(vh.x, vh.y)), fmaxf(tmin - t.x, t.x - h.t));
+        const float outside = fmaxf(fmaxf(vl.x, vl.y), fmaxf(vh.x, vh.y));
+        const float viol = fmaxf(outside, fmaxf(tmin - t.x, t.x - h.t));
         const bool hit = (viol <= 0.0f) & (id0 != src);
         h.t = hit ? t.x : h.t; h.leaf = hit ? id0 : h.leaf;
+        if (PDF && P.f[12] != 0.0f) pdf += fmaxf(outside, 0.0001f - t.x) <= 0.0f ? (t.x * t.x) * (fabsf(in) * P.f[12]) : 0.0f;
     }
     if (id1 >= 0) {   // wave-uniform (a scalar compare): the run had an odd number of rects and this is its padding
         const v2f p = oab + dab * t.y;
         const v2f lo = {P.f[6], P.f[7]}, hi = {P.f[8], P.f[9]};
         const v2f vl = lo - p, vh = p - hi;
-        const float viol = fmaxf(fmaxf(fmaxf(vl.x, vl.y), fmaxf(vh.x, vh.y)), fmaxf(tmin - t.y, t.y - h.t));
+        const float outside = fmaxf(fmaxf(vl.x, vl.y), fmaxf(vh.x, vh.y));
+        const float viol = fmaxf(outside, fmaxf(tmin - t.y, t.y - h.t));
         const bool hit = (viol <= 0.0f) & (id1 != src);
         h.t = hit ? t.y : h.t; h.leaf = hit ? id1 : h.leaf;
+        if (PDF && P.f[13] != 0.0f) pdf += fmaxf(outside, 0.0001f - t.y) <= 0.0f ? (t.y * t.y) * (fabsf(in) * P.f[13]) : 0.0f;
     }
 }
-RT_DEV void small_run(const SmallScene &ss, int first, int count, float on, float in, float oa, float da, float ob, float db, float tmin, int src, SmallHit &h) {
+template <bool PDF>
+RT_DEV void small_run(const SmallScene &ss, int first, int count, float on, float in, float oa, float da, float ob, float db, float tmin, int src, SmallHit &h, float &pdf) {
     const v2f oab = {oa, ob}, dab = {da, db};
-    for (int p = first; p < first + count; ++p) small_pair(ss.pairs[p], on, in, oab, dab, tmin, src, h);   // wave-uniform: one s_load_dwordx16
+    for (int p = first; p < first + count; ++p) small_pair<PDF>(ss.pairs[p], on, in, oab, dab, tmin, src, h, pdf);   // wave-uniform: one s_load_dwordx16
 }
 // box_hit (hittable.c:521-523 = the list scan over the sides) as one slab test, also for a box with openings: the surface is entered at the largest
 // near-plane parameter and left at the smallest far-plane parameter; a ray that starts inside (or on) the box hits the
@@ -108,22 +117,27 @@ RT_DEV void small_box(const SmallBox &B, f3 o, f3 inv, float tmin, int src, Smal
     h.t = hit ? t : h.t; h.leaf = hit ? (int)id : h.leaf;
 }
 // the records of one object space against the ray in that space
-RT_DEV void small_group_hit(const SmallScene &ss, const SmallGroup &g, f3 o, f3 d, f3 inv, float tmin, int src, SmallHit &h) {
+template <bool PDF>
+RT_DEV void small_group_hit(const SmallScene &ss, const SmallGroup &g, f3 o, f3 d, f3 inv, float tmin, int src, SmallHit &h, float &pdf) {
     if (g.box >= 0) small_box(ss.boxes[g.box], o, inv, tmin, src, h);
     int first = g.first;
-    small_run(ss, first, g.n_xy, o.z, inv.z, o.x, d.x, o.y, d.y, tmin, src, h); first += g.n_xy;
-    small_run(ss, first, g.n_xz, o.y, inv.y, o.x, d.x, o.z, d.z, tmin, src, h); first += g.n_xz;
-    small_run(ss, first, g.n_yz, o.x, inv.x, o.y, d.y, o.z, d.z, tmin, src, h);
+    small_run<PDF>(ss, first, g.n_xy, o.z, inv.z, o.x, d.x, o.y, d.y, tmin, src, h, pdf); first += g.n_xy;
+    small_run<PDF>(ss, first, g.n_xz, o.y, inv.y, o.x, d.x, o.z, d.z, tmin, src, h, pdf); first += g.n_xz;
+    small_run<PDF>(ss, first, g.n_yz, o.x, inv.x, o.y, d.y, o.z, d.z, tmin, src, h, pdf);
 }
 // hittable_list_hit (hittable_list.c:125-143) over the packed leaves.  `src` = leaf the ray starts on: a sphere left behind
 // has the roots {0, 2 tc} (rt_core.hpp sphere_leave_t), a rect or box face left behind is not tested again.
-RT_DEV SmallHit small_closest_hit(const SmallScene &ss, f3 ow, f3 dw, float tmin, int src) {
+// `pdf` (out) = sum over the light-list entries that are leaves of this pack of their pdf for this ray (fused scenes, flatten.cpp
+// mark_small_lights; 0 otherwise): what small_light_pdf_sum would return for (ow, dw), taken from the tests that run here anyway.
+template <bool PDF>
+RT_DEV SmallHit small_closest_hit(const SmallScene &ss, f3 ow, f3 dw, float tmin, int src, float &pdf) {
+    pdf = 0.0f;
     SmallHit h; h.t = 3.0e38f; h.leaf = -1;
     const f3 invw = rcp3(dw);
     // The world-space group (xform 0 sorts first, flatten.cpp build_small_pack) runs on the world ray as it is; written as
     // one loop with `o = ow; if (xform) o = ...` the compiler copies nine registers per group to have something to overwrite.
     int gi = 0;
-    if (ss.n_groups > 0 && ss.groups[0].xform == 0) { small_group_hit(ss, ss.groups[0], ow, dw, invw, tmin, src, h); gi = 1; }
+    if (ss.n_groups > 0 && ss.groups[0].xform == 0) { small_group_hit<PDF>(ss, ss.groups[0], ow, dw, invw, tmin, src, h, pdf); gi = 1; }
     for (; gi < ss.n_groups; ++gi) {
         const SmallGroup g = ss.groups[gi];                      // wave-uniform
         const SmallXform x = ss.xforms[g.xform];
@@ -133,7 +147,8 @@ RT_DEV SmallHit small_closest_hit(const SmallScene &ss, f3 ow, f3 dw, float tmin
             d = f3mk(x.m[0] * dw.x + x.m[2] * dw.z, dw.y, x.m[6] * dw.x + x.m[8] * dw.z);
             inv = f3mk(__builtin_amdgcn_rcpf(d.x), invw.y, __builtin_amdgcn_rcpf(d.z));
         } else { o = xform_point(x, ow); d = xform_dir(x, dw); inv = rcp3(d); }
-        small_group_hit(ss, g, o, d, inv, tmin, src, h);
+        float no_pdf = 0.0f;                                      // (lights are matched to world-space leaves only)
+        small_group_hit<false>(ss, g, o, d, inv, tmin, src, h, no_pdf);
     }
     if (ss.n_spheres > 0) {                                      // world space, closest-approach form (rt_core.hpp sphere_t<float>)
         for (int s = 0; s < ss.n_spheres; ++s) {                 // |dw| = 1 (every ray of this kernel): the quadratic's a is 1
@@ -150,6 +165,15 @@ RT_DEV SmallHit small_closest_hit(const SmallScene &ss, f3 ow, f3 dw, float tmin
             const float t = ok0 ? t0 : t1;
             const bool hit = (from | (q >= 0.0f)) & (ok0 | ok1);
             h.t = hit ? t : h.t; h.leaf = hit ? id : h.leaf;
+            if (PDF && sp.pdf_k != 0.0f) {                           // wave-uniform: this sphere is a light-list entry (hittable.c:760-768)
+                const float need = 0.001f - tc;                      // the far root tc + sqrt(q) decides alone: small_light_pdf_one
+                const bool seen = !(q < 0.0f) & (!(need > 0.0f) | !(q < need * need));
+                // 1 / (2 pi (1 - cos_max)), cos_max = sqrt(1 - r^2 / d^2):  1 / (1 - c) = (1 + c) d^2 / r^2, so the value is
+                // (d^2 + sqrt((d^2 - r^2) d^2)) / (2 pi r^2) -- one square root, no reciprocal; d^2 = |l|^2 + tc^2 for a unit
+                // direction.  An origin inside the sphere gives NaN like the reference's sqrt of a negative number.
+                const float d2 = __builtin_fmaf(tc, tc, len2(l));
+                pdf += seen ? (d2 + __builtin_amdgcn_sqrtf((d2 - sp.r2) * d2)) * sp.pdf_k : 0.0f;
+            }
         }
     }
     return h;
@@ -228,7 +252,9 @@ RT_DEV f3 small_light_sample(const SceneT<float> &sc, int pick, f3 o, float r1, 
 // PROBE = true: the one-sample cost probe of launch_pathtrace_small (its own kernel name in profiles): writes the rays of
 // each tile to tile_cost and nothing else.
 // LENS = false: pinhole camera (aperture 0, every reference scene but Book 1 / Book 2 random): no lens sample in the loop.
-template <int INTEGRATOR, bool LENS, bool PROBE>
+// FUSED = true (03 integrator only): every light of the scene is a leaf of the pack and its pdf comes out of the next ray's
+// intersection (flatten.cpp mark_small_lights); the stand-alone light-pdf loop is then not even compiled in.
+template <int INTEGRATOR, bool LENS, bool PROBE, bool FUSED>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) k_pathtrace_small(SmallScene ss, SceneT<float> sc, CameraT<float> cam, RenderParams P,
                                                           float4 *__restrict__ accum, unsigned long long *__restrict__ counters,
                                                           const int *__restrict__ tile_perm, int *__restrict__ tile_cost,
@@ -284,6 +310,12 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) k
     int depth = 0, src = -1, cur_pix = 0;
     uint32_t s_cur = 0, pixel = 0;
     bool alive = false;
+    // Fused light pdfs (03 integrator, scenes whose lights are leaves of the pack): a diffuse bounce leaves the scattering pdf of
+    // its new direction in `pend` and multiplies the throughput by the albedo only; the mixture pdf pdf.c:119-121 needs the
+    // light-list pdf of that direction, which the NEXT iteration's intersection of that very ray delivers (`pdf_ray`), and the
+    // throughput is completed there -- before anything reads it.  pend = 0: nothing pending.
+    constexpr bool fused = FUSED && INTEGRATOR == 0 && !RG;
+    float pend = 0.0f;
     // Path numbers: q = sample * 64 + pixel.  PAIRS (A/B build): a pinhole primary ray needs TWO random numbers and a Philox block has
     // four, so samples 2k and 2k + 1 of a pixel share the block keyed (pixel, k, camera): words x, y jitter the even sample,
     // z, w the odd one -- still a pure function of (pixel, sample).  Work is numbered in UNITS u = layer * 64 + pixel of two
@@ -381,7 +413,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) k
             rd = b0d; b0d = b1d; b0q = b1q;
             if (LENS) { ro = b0o; b0o = b1o; } else ro = f3mk(cam.origin[0], cam.origin[1], cam.origin[2]);
             T = f3mk(1, 1, 1);
-            depth = 0; src = -1;
+            depth = 0; src = -1; pend = 0.0f;
             alive = rd.x != 0.0f || rd.y != 0.0f || rd.z != 0.0f;          // a pixel outside the image: nothing to trace
         }
         // (a buffered ray may be void -- a pixel outside the image, the half of a unit outside the sample range: a wave whose lanes
@@ -391,11 +423,19 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) k
         ++iters;
         SmallHit h; h.t = 0.0f; h.leaf = -1;
         if (alive) {
-            h = small_closest_hit(ss, ro, rd, 0.001f, src);           // ray.c:56
+            float pdf_ray;
+            h = small_closest_hit<fused>(ss, ro, rd, 0.001f, src, pdf_ray);  // ray.c:56
 #if RT_EXP == 1   // cost probe: intersection twice (second call perturbed so it is not CSE'd)
-            { const SmallHit h2 = small_closest_hit(ss, ro, rd, 0.001f + 1e-9f * (float)iters, src); if (h2.t < h.t) h = h2; }
+            { float p2; const SmallHit h2 = small_closest_hit<false>(ss, ro, rd, 0.001f + 1e-9f * (float)iters, src, p2); if (h2.t < h.t) h = h2; }
 #endif
             ++nrays;
+            if (fused && pend > 0.0f) {                               // complete the previous bounce: T *= pdf_cos / pdf_val (ray.c:80-83)
+                // (pend > 0 and a cosine weight > 0 make pdf_val > 0; a pdf_val of 0 or NaN -- cosine weight 0, a ray from inside a light
+                // sphere -- turns T into inf / NaN like the reference's 0/0, and a non-finite path sum is dropped where the path ends)
+                const float pdf_val = P.light_weight_each * pdf_ray + P.cosine_weight * pend;
+                T = T * (pend * __builtin_amdgcn_rcpf(pdf_val));
+                pend = 0.0f;
+            }
         }
 #if RT_SMALL_REGROUP
         if (RG) {
@@ -492,6 +532,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) k
 #endif
                     nd = nd * __builtin_amdgcn_rsqf(len2(nd));              // unit from here on: the pdfs and the next bounce's tests drop |v|
                     const float pdf_cos = lambert_pdf(n, nd);                         // pdf.c:100-103 == material.c:205-208
+                    if (fused) {                                            // the light-list pdf of nd arrives with the next intersection
+                        if (!(pdf_cos > 0.0f)) done = true;
+                        else { T = T * col; pend = pdf_cos; }
+                    } else {
                     const float pdf_light = sc.n_lights > 0 ? small_light_pdf_sum(sc, p, nd) : 0.0f;   // x 1 / n_lights below
 #if RT_EXP == 5   // cost probe: the light-list pdf twice
                     const float pdf_light2 = sc.n_lights > 0 ? small_light_pdf_sum(sc, p + f3mk(1e-9f * (float)iters, 0, 0), nd) : 0.0f;
@@ -502,6 +546,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) k
                     // scattering pdf 0: the reference recurses and multiplies by 0; pdf_val 0: 0/0 (scrubbed) -- nothing more arrives
                     if (!(pdf_cos > 0.0f) || !(pdf_val > 0.0f)) done = true;
                     else T = T * (col * (pdf_cos * __builtin_amdgcn_rcpf(pdf_val)));
+                    }
                 }
                 ro = p; rd = nd; src = h.leaf;
             }
@@ -588,9 +633,13 @@ template <bool PROBE>
 static void launch_small(const SmallScene &ss, const SceneT<float> &sc, const CameraT<float> &cam, const RenderParams &p, float4 *accum,
                          unsigned long long *counters, const int *perm, int *cost, float4 *partial, int log2_chunks, hipStream_t stream) {
     const unsigned blocks = (unsigned)((((long long)p.n_tiles << log2_chunks) + 3) / 4);
-#define RT_SMALL_LAUNCH(I, L) hipLaunchKernelGGL((k_pathtrace_small<I, L, PROBE>), dim3(blocks), dim3(256), 0, stream, ss, sc, cam, p, accum, counters, perm, cost, partial, log2_chunks)
+#define RT_SMALL_LAUNCH(I, L) hipLaunchKernelGGL((k_pathtrace_small<I, L, PROBE, false>), dim3(blocks), dim3(256), 0, stream, ss, sc, cam, p, accum, counters, perm, cost, partial, log2_chunks)
     const bool lens = cam.lens_radius > 0.0f;
-    if (p.integrator == 0) { if (lens) RT_SMALL_LAUNCH(0, true); else RT_SMALL_LAUNCH(0, false); }
+    if (p.integrator == 0 && ss.fused_lights && !RT_SMALL_REGROUP) {
+        if (lens) hipLaunchKernelGGL((k_pathtrace_small<0, true, PROBE, true>), dim3(blocks), dim3(256), 0, stream, ss, sc, cam, p, accum, counters, perm, cost, partial, log2_chunks);
+        else hipLaunchKernelGGL((k_pathtrace_small<0, false, PROBE, true>), dim3(blocks), dim3(256), 0, stream, ss, sc, cam, p, accum, counters, perm, cost, partial, log2_chunks);
+    }
+    else if (p.integrator == 0) { if (lens) RT_SMALL_LAUNCH(0, true); else RT_SMALL_LAUNCH(0, false); }
     else if (p.integrator == 1) { if (lens) RT_SMALL_LAUNCH(1, true); else RT_SMALL_LAUNCH(1, false); }
     else { if (lens) RT_SMALL_LAUNCH(2, true); else RT_SMALL_LAUNCH(2, false); }
 #undef RT_SMALL_LAUNCH

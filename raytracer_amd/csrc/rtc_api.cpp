@@ -221,6 +221,7 @@ static rtc_scene *upload_scene(rtc_scene *s, const char *who) {
         m.xforms = (const SmallXform *)s->small_xforms.p;
         m.n_rects = fs.small_n_rects; m.n_pairs = (int)fs.small_pairs.size(); m.n_groups = (int)fs.small_groups.size(); m.n_spheres = (int)fs.small_spheres.size();
         m.n_xforms = (int)fs.small_xforms.size(); m.n_leaves = (int)fs.small_shade.size(); m.any_fuzz = fs.small_any_fuzz;
+        m.fused_lights = fs.small_fused;
     }
     if (e != hipSuccess) { g_error = std::string(who) + ": upload failed: " + hipGetErrorString(e); delete s; return nullptr; }
     return s;
@@ -285,6 +286,17 @@ int rtc_scene_bvh_info(const rtc_scene *scene, long long *out4) {
     const FlatScene &fs = scene->flat;
     out4[0] = (long long)fs.nodes.size(); out4[1] = (long long)fs.bleaves.size(); out4[2] = fs.bvh_depth;
     out4[3] = (long long)(fs.nodes.size() * sizeof(BvhNode) + fs.bleaves.size() * (sizeof(BLeaf) + sizeof(int)));
+    return RTC_OK;
+}
+
+int rtc_scene_small_info(const rtc_scene *scene, int *out8) {
+    if (!scene || !out8) return fail(RTC_ERR_ARG, "rtc_scene_small_info: null argument");
+    const FlatScene &fs = scene->flat;
+    int fused_rects = 0, fused_spheres = 0;
+    for (const SmallPair &P : fs.small_pairs) fused_rects += (P.f[12] != 0.0f) + (P.f[13] != 0.0f);
+    for (const SmallSphere &sp : fs.small_spheres) fused_spheres += sp.pdf_k != 0.0f;
+    out8[0] = fs.small_ok; out8[1] = (int)fs.small_pairs.size(); out8[2] = (int)fs.small_groups.size(); out8[3] = (int)fs.small_boxes.size();
+    out8[4] = (int)fs.small_spheres.size(); out8[5] = fs.small_fused; out8[6] = fused_rects; out8[7] = fused_spheres;
     return RTC_OK;
 }
 

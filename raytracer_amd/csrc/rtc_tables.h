@@ -103,9 +103,11 @@ template <typename R> struct SceneT {
 //   SmallPair  : 64 B = TWO rects of one (space, axis) run, read with ONE s_load_dwordx16 (the index is wave-uniform);
 //                f = k0 k1 | lo_a0 lo_b0 | hi_a0 hi_b0 | lo_a1 lo_b1 | hi_a1 hi_b1   (a,b = in-plane axes: XY->x,y
 //                XZ->x,z  YZ->y,z; (lo_a, lo_b) and (hi_a, hi_b) sit in aligned register pairs for packed FP32 math);
-//                | id0 id1 (int bits);  a run of odd length ends with a never-hit rect (lo = +inf)
+//                | id0 id1 (int bits) | f[12], f[13] = 1 / area when that rect is a light-list entry (else 0);  a run of odd
+//                length ends with a never-hit rect (lo = +inf)
 //   SmallGroup : 32 B per object space: xform id, first pair, pairs per axis
-//   SmallSphere: 16 B, world space (rotations/translations only move the centre): cx cy cz r*r
+//   SmallSphere: 32 B, world space (rotations/translations only move the centre): cx cy cz r*r | pdf_k = (times the sphere is
+//                listed in `lights`) / (2 pi r^2), 0 for a sphere that is no light-list entry
 //   SmallShade : 48 B, gathered per lane from LDS by the winning leaf: world-space outward normal (rect) or centre and
 //                1/r (sphere), resolved material (solid colour already looked up), flags
 //   SmallXform : the translate/rotate wrapper stack of a leaf collapsed to x_obj = M x_world + b (M a rotation)
@@ -122,7 +124,7 @@ struct alignas(32) SmallGroup { int xform, first, n_xy, n_xz, n_yz, box, rot_y, 
 // tests (~78).  ids_lo / ids_hi = leaf ids of the x, y, z faces at lo / hi, one byte each, 0xff = the box has no such
 // face (a ray passes through the opening).
 struct alignas(32) SmallBox { float lo[3], hi[3]; uint32_t ids_lo, ids_hi; };
-struct alignas(16) SmallSphere { float c[3]; float r2; };
+struct alignas(32) SmallSphere { float c[3]; float r2; float pdf_k; float pad[3]; };
 struct alignas(16) SmallShade { uint32_t meta; float rgb[3]; float g[4]; float param; float pad[3]; };
 struct SmallXform { float m[9]; float b[3]; };
 struct SmallScene {
@@ -132,6 +134,7 @@ struct SmallScene {
     int n_rects;                                   // leaf id of sphere s = n_rects + s
     int n_leaves;                                  // n_rects + n_spheres
     int any_fuzz;                                  // some metal has fuzz > 0
+    int fused_lights;                              // every light's pdf comes out of the intersection of the next ray (flatten.cpp mark_small_lights)
 };
 
 template <typename R> struct CameraT { R origin[3], llc[3], horizontal[3], vertical[3], u[3], v[3], w[3]; R lens_radius, time0, time1; };

@@ -1008,3 +1008,31 @@ def test_full_size_4k_shards_add_up(gpu):
         assert np.allclose(acc[..., :3], full[..., :3], rtol=1e-5, atol=1e-6)
     finally:
         sc.close()
+
+
+def test_light_pdf_fused_into_the_intersection_equals_the_light_loop(gpu, monkeypatch):
+    """Cornell's lights (the ceiling rect under its flip_face, the glass sphere) are leaves of the small-scene pack, so the bounce
+    loop takes hittable_list_pdf_value (hittable_list.c:165-172, hittable.c:760-788) from the NEXT ray's intersection instead of a
+    loop over the lights (flatten.cpp mark_small_lights, k_pathtrace_small<..., FUSED>).  RTC_SMALL_NO_FUSE=1 at scene build keeps
+    the loop: same Philox draws, same paths -- the sums agree to FP32 rounding of the reordered products; ray counts to 1e-5 (a
+    path whose mixture pdf underflows to 0 is cut one bounce later by the fused form: its throughput is already inf / NaN)."""
+    imgs, rays = [], []
+    for no_fuse in (False, True):
+        if no_fuse:
+            monkeypatch.setenv("RTC_SMALL_NO_FUSE", "1")
+        sc, cam, view = gpu.build_named_scene("cornell", aspect=1.5)
+        try:
+            for w in (0.1, 0.5):
+                acc, st = sc.render(cam, gpu.Settings(192, 128, 96, 10, 0, seed=11, mixture_light_weight=w))
+                assert st["kernel_used"] == 2
+                imgs.append(acc[..., :3].copy()); rays.append(st["rays"])
+        finally:
+            sc.close()
+    for k in range(2):
+        a, b = imgs[k], imgs[2 + k]
+        assert abs(rays[k] - rays[2 + k]) <= 1e-5 * rays[k]
+        assert np.isfinite(a).all() and a.sum() > 0
+        # per pixel: 96 samples of products that differ in the last bits; a path that lands on the other side of a comparison is rare
+        rel = np.abs(a - b).sum() / a.sum()
+        print(f"fused vs loop, weight {(0.1, 0.5)[k]}: sum |d| / sum = {rel:.2e}, max |d| = {np.abs(a - b).max():.3e}")
+        assert rel <= 2e-5

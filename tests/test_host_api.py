@@ -251,3 +251,35 @@ print("freed", len(ra.api.SCENES))
     env = dict(os.environ, MALLOC_CHECK_="3", MALLOC_PERTURB_="165")   # glibc: abort on a double free, poison freed memory
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, timeout=300, env=env)
     assert out.returncode == 0 and b"freed 15" in out.stdout, out.stderr.decode()[-2000:]
+
+
+def test_lights_that_are_leaves_of_the_small_pack(monkeypatch):
+    """flatten.cpp mark_small_lights: Cornell's two lights (ceiling rect under flip_face, glass sphere) are world-space leaves of the
+    pack -> their pdfs ride on the intersection; a light that is a face of a slab-tested box, a light behind a translate, or a light
+    that is not in the world keeps the explicit loop for the whole scene; RTC_SMALL_NO_FUSE switches the matching off."""
+    import raytracer_amd.api as A
+    L, v3 = A.lib(), A.v3
+    sc, cam, view = A.build_named_scene("cornell", host_only=True)
+    info = sc.small_info(); sc.close()
+    assert info["eligible"] == 1 and info["fused"] == 1 and info["fused_rects"] == 1 and info["fused_spheres"] == 1
+
+    # a rect light alone in the world, listed once / twice; and the same light not in the world at all
+    for twice, in_world in ((False, True), (True, True), (False, False)):
+        world = L.hittable_list_new(8)
+        lights = L.hittable_list_new_no_gc(4)
+        white = L.material_lambertian_new_from_color(v3((0.7, 0.7, 0.7)))
+        lamp = L.material_light_new_from_color(v3((8, 8, 8)))
+        L.hittable_sphere_new(world, v3((0, -100, 0)), 100.0, white)
+        other = L.hittable_list_new(2)
+        light = L.hittable_rect_new(world if in_world else other, -1.0, 1.0, 0.0, 0.0, -1.0, 1.0, 3.0, 1, lamp)   # XZ rect at y = 3
+        L.hittable_list_add(lights, light)
+        if twice:
+            L.hittable_list_add(lights, light)
+        sc = A.Scene(world, lights, (0, 0, 0), host_only=True)
+        info = sc.small_info(); sc.close()
+        assert info["eligible"] == 1
+        assert info["fused"] == (1 if in_world else 0) and info["fused_rects"] == (1 if in_world else 0), (twice, in_world, info)
+    monkeypatch.setenv("RTC_SMALL_NO_FUSE", "1")
+    sc, cam, view = A.build_named_scene("cornell", host_only=True)
+    info = sc.small_info(); sc.close()
+    assert info["fused"] == 0 and info["fused_rects"] == 0 and info["fused_spheres"] == 0

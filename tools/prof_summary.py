@@ -1,11 +1,11 @@
 """Summarise a tools/profile.sh output directory: kernel stats + per-launch PMC means for the path-tracing kernel."""
-import collections, csv, glob, json, os, sys
+import collections, csv, glob, json, os, re, sys
+PROBE = re.compile(r"k_pathtrace_small<\d+, \w+, true")   # third template argument: the one-sample cost probe of the small kernel
 d = sys.argv[1]
 pat = sys.argv[2] if len(sys.argv) > 2 else "pathtrace"   # substring of the kernel name to summarise
 out = {}
 for row in csv.DictReader(open(os.path.join(d, "trace", "trace_kernel_stats.csv"))):
-    if pat in row["Name"] and ", true>" not in row["Name"]:       # ", true>" = the one-sample cost probe of the small kernel
-        import re
+    if pat in row["Name"] and not PROBE.search(row["Name"]):
         out["kernel"] = re.search(r"(k_\w+(<[\w, ]+>)?)", row["Name"]).group(1)
         out["calls"] = int(row["Calls"]); out["avg_ms"] = float(row["AverageNs"]) / 1e6
         out["min_ms"] = float(row["MinNs"]) / 1e6; out["max_ms"] = float(row["MaxNs"]) / 1e6
@@ -13,7 +13,7 @@ pmc = {}
 for f in sorted(glob.glob(os.path.join(d, "pmc_*", "*_counter_collection.csv"))):
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
-        if pat in r["Kernel_Name"] and ", true>" not in r["Kernel_Name"]:
+        if pat in r["Kernel_Name"] and not PROBE.search(r["Kernel_Name"]):
             agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
             out["vgpr"] = r.get("VGPR_Count"); out["sgpr"] = r.get("SGPR_Count"); out["lds"] = r.get("LDS_Block_Size")
     for k, v in agg.items():

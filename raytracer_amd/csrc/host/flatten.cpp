@@ -548,7 +548,10 @@ void build_leaf_shade(FlatScene &fs) {
         bool general = p.type != RTC_PRIM_RECT && p.type != RTC_PRIM_SPHERE;
         if (!normal_ok || ((m.type == RTC_MAT_DIELECTRIC || m.type == RTC_MAT_LIGHT) && !front_ok)) general = true;   // replay the chain (resolve_hit)
         if (m.type == RTC_MAT_METAL) { for (int k = 0; k < 3; k++) S.rgb[k] = (float)m.albedo[k]; S.param = (float)m.param; }
-        else if (m.type == RTC_MAT_DIELECTRIC) { S.rgb[0] = S.rgb[1] = S.rgb[2] = 1.0f; S.param = (float)m.param; }
+        else if (m.type == RTC_MAT_DIELECTRIC) {   // pad[0] = 1 / ir, pad[1] = Schlick's r0 = ((1 - ir) / (1 + ir))^2 (the same for ir and 1 / ir)
+            S.rgb[0] = S.rgb[1] = S.rgb[2] = 1.0f; S.param = (float)m.param; S.pad[0] = (float)(1.0 / m.param);
+            const double r = (1.0 - m.param) / (1.0 + m.param); S.pad[1] = (float)(r * r);
+        }
         else if (m.type == RTC_MAT_ISOTROPIC || m.tex < 0 || fs.textures[m.tex].type != RTC_TEX_SOLID) general = true;
         else for (int k = 0; k < 3; k++) S.rgb[k] = (float)fs.textures[m.tex].v[k];
         if (p.type == RTC_PRIM_RECT) {
@@ -632,7 +635,10 @@ void build_small_pack(FlatScene &fs) {
         const double *M = xfd[x].data(), *b = M + 9;
         S.meta = (uint32_t)m.type | (wrapped ? RTC_SF_FORCED_FRONT : 0u) | (flip ? RTC_SF_FLIP : 0u);
         if (m.type == RTC_MAT_METAL) { for (int k = 0; k < 3; k++) S.rgb[k] = (float)m.albedo[k]; S.param = (float)m.param; any_fuzz |= m.param > 0; }
-        else if (m.type == RTC_MAT_DIELECTRIC) { S.rgb[0] = S.rgb[1] = S.rgb[2] = 1.0f; S.param = (float)m.param; }
+        else if (m.type == RTC_MAT_DIELECTRIC) {   // pad[0] = 1 / ir, pad[1] = Schlick's r0 = ((1 - ir) / (1 + ir))^2 (the same for ir and 1 / ir)
+            S.rgb[0] = S.rgb[1] = S.rgb[2] = 1.0f; S.param = (float)m.param; S.pad[0] = (float)(1.0 / m.param);
+            const double r = (1.0 - m.param) / (1.0 + m.param); S.pad[1] = (float)(r * r);
+        }
         else {
             if (m.tex < 0 || fs.textures[m.tex].type != RTC_TEX_SOLID) return;
             for (int k = 0; k < 3; k++) S.rgb[k] = (float)fs.textures[m.tex].v[k];

@@ -125,7 +125,7 @@ struct alignas(32) SmallGroup { int xform, first, n_xy, n_xz, n_yz, box, rot_y, 
 // face (a ray passes through the opening).
 struct alignas(32) SmallBox { float lo[3], hi[3]; uint32_t ids_lo, ids_hi; };
 struct alignas(32) SmallSphere { float c[3]; float r2; float pdf_k; float pad[3]; };
-struct alignas(16) SmallShade { uint32_t meta; float rgb[3]; float g[4]; float param; float pad[3]; };
+struct alignas(16) SmallShade { uint32_t meta; float rgb[3]; float g[4]; float param; float pad[3]; };   // param: fuzz / ir; glass: pad[0] = 1 / ir, pad[1] = Schlick r0
 struct SmallXform { float m[9]; float b[3]; };
 struct SmallScene {
     const SmallPair *pairs; const SmallGroup *groups; const SmallSphere *spheres; const SmallShade *shade; const SmallXform *xforms;

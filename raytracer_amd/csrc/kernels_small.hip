@@ -66,6 +66,34 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 // A rect that is also an entry of the lights list (P.f[12] / P.f[13] = 1 / area, flatten.cpp mark_small_lights; a wave-uniform
 // branch) adds its pdf for THIS ray to `pdf` on the way: hittable_pdf_value (hittable.c:772-788) is this very plane test with
 // tmin 1e-4 and no upper bound, value t^2 |1/d_n| / area for a unit direction (small_light_pdf_one below is the stand-alone form).
+// RT_SMALL_SCALAR_PAIR=0: A/B build with the two in-plane axes of a rect test in packed FP32 instructions (v_pk_fma_f32 ...), the
+// round-1 form.  A packed instruction issues in 1.4x the time of a plain one (tools/ubench/valu_rates) and every run pays six
+// moves to build the aligned register pairs: the plain form below is 1-2 % faster on the headline render (17.95 -> 17.57 ms).
+#ifndef RT_SMALL_SCALAR_PAIR
+#define RT_SMALL_SCALAR_PAIR 1
+#endif
+#if RT_SMALL_SCALAR_PAIR
+template <bool PDF>
+RT_DEV void small_rect(float k, float lo_a, float lo_b, float hi_a, float hi_b, int id, float inv_area, float on, float in, float oa, float da, float ob, float db,
+                       float tmin, int src, SmallHit &h, float &pdf) {
+    const float t = (k - on) * in;
+    const float pa = __builtin_fmaf(da, t, oa), pb = __builtin_fmaf(db, t, ob);
+    const float outside = fmaxf(fmaxf(lo_a - pa, pa - hi_a), fmaxf(lo_b - pb, pb - hi_b));
+    const float viol = fmaxf(outside, fmaxf(tmin - t, t - h.t));
+    const bool hit = (viol <= 0.0f) & (id != src);
+    h.t = hit ? t : h.t; h.leaf = hit ? id : h.leaf;
+    if (PDF && inv_area != 0.0f) pdf += fmaxf(outside, 0.0001f - t) <= 0.0f ? (t * t) * (fabsf(in) * inv_area) : 0.0f;
+}
+template <bool PDF>
+RT_DEV void small_run(const SmallScene &ss, int first, int count, float on, float in, float oa, float da, float ob, float db, float tmin, int src, SmallHit &h, float &pdf) {
+    for (int p = first; p < first + count; ++p) {                 // wave-uniform: one s_load_dwordx16
+        const SmallPair &P = ss.pairs[p];
+        small_rect<PDF>(P.f[0], P.f[2], P.f[3], P.f[4], P.f[5], __float_as_int(P.f[10]), P.f[12], on, in, oa, da, ob, db, tmin, src, h, pdf);
+        if (__float_as_int(P.f[11]) >= 0)
+            small_rect<PDF>(P.f[1], P.f[6], P.f[7], P.f[8], P.f[9], __float_as_int(P.f[11]), P.f[13], on, in, oa, da, ob, db, tmin, src, h, pdf);
+    }
+}
+#else
 template <bool PDF>
 RT_DEV void small_pair(const SmallPair &P, float on, float in, v2f oab, v2f dab, float tmin, int src, SmallHit &h, float &pdf) {
     const v2f k = {P.f[0], P.f[1]};
@@ -97,6 +125,7 @@ RT_DEV void small_run(const SmallScene &ss, int first, int count, float on, floa
     const v2f oab = {oa, ob}, dab = {da, db};
     for (int p = first; p < first + count; ++p) small_pair<PDF>(ss.pairs[p], on, in, oab, dab, tmin, src, h, pdf);   // wave-uniform: one s_load_dwordx16
 }
+#endif
 // box_hit (hittable.c:521-523 = the list scan over the sides) as one slab test, also for a box with openings: the surface is entered at the largest
 // near-plane parameter and left at the smallest far-plane parameter; a ray that starts inside (or on) the box hits the
 // exit face.  The face gives the leaf id, so shading sees the same record as after six rect tests.

@@ -16,7 +16,7 @@
 //   * material / pdf dispatch is a switch on the record's type; lambertian sampling uses n + uniform-sphere (the same
 //     cosine law as onb.c + random_cosine_direction, without building the basis), the mixture pdf of pdf.c:119-121;
 //   * Philox4x32-7 on (pixel, sample, bounce); 2 blocks per path start are not needed here (no lens, no moving leaf).
-// 77 VGPRs -> 6 waves per SIMD (amdgpu_waves_per_eu), no VGPR spills, 6 KB of LDS (shading records + tile sums); the SIMDs issue VALU instructions all the time, so what
+// 72 VGPRs -> 7 waves per SIMD (amdgpu_waves_per_eu), no VGPR spills, 6 KB of LDS (shading records + tile sums); the SIMDs issue VALU instructions all the time, so what
 // is left is the instruction count and the divergence of the material switch (DESIGN.md 3.1 has the cycle budget).
 #include <hip/hip_runtime.h>
 
@@ -34,6 +34,12 @@
 // hand-out costs more scalar and vector bookkeeping than the saved block, so the product is built without it.
 #ifndef RT_SMALL_PAIRS
 #define RT_SMALL_PAIRS 0
+#endif
+// waves per SIMD the kernel is compiled for (registers per lane = 512 / waves, rounded down to a multiple of 8)
+// (measured on the r02 kernel, 1080p / 1024^2: 5 waves 17.66 / 14.33 ms, 6: 17.69 / 14.35, 7: 17.37 / 14.04 -- 72 VGPRs, no VGPR spills --
+// 8: 17.67 / 14.40 with 4 spilled registers)
+#ifndef RT_SMALL_WAVES
+#define RT_SMALL_WAVES 7
 #endif
 // RT_SMALL_FMA_SLAB=0: A/B build with the box slab planes as (k - o) * inv (two instructions per plane) instead of one FMA
 // (measured: the FMA form is 0.9 % faster, 17.98 -> 17.83 ms)
@@ -299,7 +305,7 @@ RT_DEV f3 small_light_sample(const SceneT<float> &sc, int pick, f3 o, float r1, 
 // FUSED = true (03 integrator only): every light of the scene is a leaf of the pack and its pdf comes out of the next ray's
 // intersection (flatten.cpp mark_small_lights); the stand-alone light-pdf loop is then not even compiled in.
 template <int INTEGRATOR, bool LENS, bool PROBE, bool FUSED>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) k_pathtrace_small(SmallScene ss, SceneT<float> sc, CameraT<float> cam, RenderParams P,
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RT_SMALL_WAVES))) k_pathtrace_small(SmallScene ss, SceneT<float> sc, CameraT<float> cam, RenderParams P,
                                                           float4 *__restrict__ accum, unsigned long long *__restrict__ counters,
                                                           const int *__restrict__ tile_perm, int *__restrict__ tile_cost,
                                                           float4 *__restrict__ partial, int log2_chunks) {

@@ -24,17 +24,6 @@
 #include "kernels.h"
 
 
-// RT_SMALL_REGROUP=1: A/B build that regroups the paths of a workgroup by material between intersection and shading
-// (DESIGN.md 3.1 has the measurement; the product is built without it).
-#ifndef RT_SMALL_REGROUP
-#define RT_SMALL_REGROUP 0
-#endif
-// RT_SMALL_PAIRS=1: A/B build in which samples 2k and 2k + 1 of a pixel share one camera Philox block (pinhole cameras need
-// two of its four words per primary ray).  Measured 2.5 % SLOWER than a block per primary ray: the unit
-// hand-out costs more scalar and vector bookkeeping than the saved block, so the product is built without it.
-#ifndef RT_SMALL_PAIRS
-#define RT_SMALL_PAIRS 0
-#endif
 // waves per SIMD the kernel is compiled for (registers per lane = 512 / waves, rounded down to a multiple of 8)
 // (measured on the r02 kernel, 1080p / 1024^2: 5 waves 17.66 / 14.33 ms, 6: 17.69 / 14.35, 7: 17.37 / 14.04 -- 72 VGPRs, no VGPR spills --
 // 8: 17.67 / 14.40 with 4 spilled registers)
@@ -304,6 +293,8 @@ RT_DEV f3 small_light_sample(const SceneT<float> &sc, int pick, f3 o, float r1, 
 // LENS = false: pinhole camera (aperture 0, every reference scene but Book 1 / Book 2 random): no lens sample in the loop.
 // FUSED = true (03 integrator only): every light of the scene is a leaf of the pack and its pdf comes out of the next ray's
 // intersection (flatten.cpp mark_small_lights); the stand-alone light-pdf loop is then not even compiled in.
+// (Two more variants were built, measured and taken out again -- the paths of a workgroup regrouped by material through LDS, +32 %;
+// one camera Philox block per sample pair, +2.5 %: DESIGN.md 3.1, profiles/r02a_regroup; the code is in the history up to 9791647.)
 template <int INTEGRATOR, bool LENS, bool PROBE, bool FUSED>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RT_SMALL_WAVES))) k_pathtrace_small(SmallScene ss, SceneT<float> sc, CameraT<float> cam, RenderParams P,
                                                           float4 *__restrict__ accum, unsigned long long *__restrict__ counters,
@@ -317,14 +308,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RT_SMA
     }
     __syncthreads();
     const int lane = threadIdx.x & 63;
-    // Regrouping A/B (RT_SMALL_REGROUP): between intersection and shading the 256 paths of the workgroup are sorted by
-    // material class through LDS and MIGRATE to the lane at their sorted position, so that a wave shades one material.
-    constexpr bool RG = RT_SMALL_REGROUP && !PROBE && INTEGRATOR == 0 && !LENS;
-    constexpr bool PAIRS = RT_SMALL_PAIRS && !LENS;
     // work item = (tile, chunk of the sample range): 2^log2_chunks waves share a tile, each with its own samples
-    int item = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const bool idle_wave = item >= (P.n_tiles << log2_chunks);   // wave-uniform
-    if (idle_wave) { if (!RG) return; item = 0; }                // (regrouping: the wave stays, it hosts the paths of the others)
+    const int item = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (item >= (P.n_tiles << log2_chunks)) return;              // wave-uniform
     int tile = item >> log2_chunks;
     const int chunk = item & ((1 << log2_chunks) - 1);
     if (!PROBE && tile_perm) tile = tile_perm[tile];   // heaviest tiles first (launch_pathtrace_small)
@@ -342,15 +328,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RT_SMA
     float *const tile_sum = lds_sum[threadIdx.x >> 6];
     tile_sum[lane] = 0.0f; tile_sum[64 + lane] = 0.0f; tile_sum[128 + lane] = 0.0f;
     const int tx0 = (tile % P.tiles_x) * 8, ty0 = (tile / P.tiles_x) * 8;
-    const int S = s_hi - s_lo, n_paths = idle_wave ? 0 : 64 * S;
-#if RT_SMALL_REGROUP
-    __shared__ float4 xbuf[3 * 256];                                      // one 48-byte path record per lane of the workgroup
-    __shared__ int xcnt[4][4];                                            // [wave][class] lanes
-    __shared__ int xtile[4][2];                                           // tile origin of each wave's work item
-    __shared__ float xsum_guard;                                          // (keeps the arrays apart in the map file)
-    (void)xsum_guard;
-    if (RG) { if (lane == 0) { xtile[threadIdx.x >> 6][0] = tx0; xtile[threadIdx.x >> 6][1] = ty0; } __syncthreads(); }
-#endif
+    const int S = s_hi - s_lo, n_paths = 64 * S;
     const float inv_w = 1.0f / (float)(P.width - 1), inv_h = 1.0f / (float)(P.height - 1);
     const f3 bg = f3mk(sc.background[0], sc.background[1], sc.background[2]);
 
@@ -364,24 +342,15 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RT_SMA
     // its new direction in `pend` and multiplies the throughput by the albedo only; the mixture pdf pdf.c:119-121 needs the
     // light-list pdf of that direction, which the NEXT iteration's intersection of that very ray delivers (`pdf_ray`), and the
     // throughput is completed there -- before anything reads it.  pend = 0: nothing pending.
-    constexpr bool fused = FUSED && INTEGRATOR == 0 && !RG;
+    constexpr bool fused = FUSED && INTEGRATOR == 0;
     float pend = 0.0f;
-    // Path numbers: q = sample * 64 + pixel.  PAIRS (A/B build): a pinhole primary ray needs TWO random numbers and a Philox block has
-    // four, so samples 2k and 2k + 1 of a pixel share the block keyed (pixel, k, camera): words x, y jitter the even sample,
-    // z, w the odd one -- still a pure function of (pixel, sample).  Work is numbered in UNITS u = layer * 64 + pixel of two
-    // samples, e = 2 u + parity names one of them; a lane that needs two rays takes a whole unit and computes ONE block for
-    // both (the camera blocks were 5 % of the render), a lane that needs one takes half a unit.  A half outside
-    // [s_lo, s_hi) (odd range ends) buffers a zero direction like a pixel outside the image.
-    const int k0 = s_lo >> 1, n_units = idle_wave ? 0 : 64 * (((s_hi + 1) >> 1) - k0);
-    auto locate = [&](int q, int &pix, uint32_t &smp) {
-        if (!PAIRS) { pix = q & 63; smp = (uint32_t)(s_lo + (q >> 6)); }
-        else { pix = (q >> 1) & 63; smp = (uint32_t)(2 * (k0 + (q >> 7)) + (q & 1)); }
-    };
+    auto locate = [&](int q, int &pix, uint32_t &smp) { pix = q & 63; smp = (uint32_t)(s_lo + (q >> 6)); };   // path number q = sample * 64 + pixel
     // Primary rays are generated ahead, two per lane (b0 is used first): a third of the lanes ends a path in every
     // iteration, so generating on demand runs the camera code (a Philox block and the ray set-up) in EVERY iteration
     // for a third of the wave; filled only when some lane has run dry, it runs every few iterations for most of it
-    // (a third buffered ray changes nothing).  6 waves/SIMD = 80 VGPRs without spills: 24.6 ms at 5 waves, 23.3 at 6, 23.6
-    // at 7 (5 spilled), 24.9 at 8 (15 spilled).  A pixel outside the image (ragged right / top edge) buffers a zero direction.
+    // (a third buffered ray changes nothing; a wave-wide batch of 64 rays through an LDS ring ran the camera code at full
+    // width but made every path start wait for an LDS read: 5.6 % slower).  A pixel outside the image (ragged right / top
+    // edge) buffers a zero direction.
     f3 b0d = rd, b1d = rd, b0o = ro, b1o = ro;
     int b0q = 0, b1q = 0, n_buf = 0;                                      // buffered paths and their numbers
     auto primary = [&](int q, f3 &o, f3 &d) {                             // main.c:150-152 + camera.c:46-53
@@ -397,12 +366,6 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RT_SMA
         const RayT<float> r = camera_ray<float>(cam, u, v, dx, dy, 0.0f);   // no leaf moves: the ray time is never read
         o = r.o; d = (px < P.width && py < P.height) ? normalize(r.d) : f3mk(0, 0, 0);   // unit directions throughout the bounce loop
     };
-    // pinhole: the unit direction through (px + jx, py + jy), camera folded on the host (RenderParams::cam_*)
-    auto pinhole_dir = [&](float fx, float fy, bool ok) -> f3 {
-        const f3 d = f3mk(P.cam_base[0] + P.cam_hs[0] * fx + P.cam_vs[0] * fy, P.cam_base[1] + P.cam_hs[1] * fx + P.cam_vs[1] * fy,
-                          P.cam_base[2] + P.cam_hs[2] * fx + P.cam_vs[2] * fy);
-        return ok ? normalize(d) : f3mk(0, 0, 0);
-    };
     // the next paths go to the lanes of `want`, in lane order
     auto hand_out = [&](bool want, int &q) -> bool {
         const unsigned long long m = __builtin_amdgcn_ballot_w64(want);
@@ -410,66 +373,26 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RT_SMA
         q_next += (int)__builtin_popcountll(m);
         return want && q < n_paths;
     };
-    int half_unit = -1;                                                   // wave-uniform: a unit whose odd half is still to be handed out
 
     for (;;) {
         if (P.max_depth <= 0) break;                                       // ray.c:52
         const bool starving = !alive && n_buf == 0;
-        if (!PAIRS) {
-            if (q_next < n_paths && __builtin_amdgcn_ballot_w64(starving) != 0) {
-                int q;
-                if (hand_out(n_buf == 0, q)) { primary(q, b0o, b0d); b0q = q; n_buf = 1; }
-                if (hand_out(n_buf == 1, q)) { primary(q, b1o, b1d); b1q = q; n_buf = 2; }
-            }
-        } else if ((q_next < n_units || half_unit >= 0) && __builtin_amdgcn_ballot_w64(starving) != 0) {
-            // One Philox block per lane and refill: whole units to the lanes with an empty buffer, half units to the lanes that lack
-            // one ray (two of them share a unit; an odd one out leaves its unit's odd half pending, and the pending half goes
-            // out first at the next refill -- to a lane that lacks one ray, else to the first empty lane).  q_next counts units.
-            const unsigned long long m2 = __builtin_amdgcn_ballot_w64(n_buf == 0), m1 = __builtin_amdgcn_ballot_w64(n_buf == 1);
-            const int n2 = (int)__builtin_popcountll(m2), n1 = (int)__builtin_popcountll(m1);
-            const int r2 = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m2 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m2, 0u));
-            const int r1 = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m1, 0u));
-            const bool have_half = half_unit >= 0, half_to_single = have_half && n1 > 0, half_to_double = have_half && n1 == 0;   // wave-uniform
-            const int n2_whole = n2 - (half_to_double ? 1 : 0);            // (n2 >= 1: some lane is starving)
-            const int fresh_singles = n1 - (half_to_single ? 1 : 0);
-            const int d_rank = r2 - (half_to_double ? 1 : 0), s_rank = r1 - (half_to_single ? 1 : 0);
-            const int next_units = q_next + n2_whole + ((fresh_singles + 1) >> 1);
-            int e, count;                                                  // 2 * unit + parity of the first ray this lane generates, rays it generates
-            if ((n_buf == 1 && half_to_single && r1 == 0) || (n_buf == 0 && half_to_double && r2 == 0)) { e = 2 * half_unit + 1; count = 1; }
-            else if (n_buf == 0) { e = 2 * (q_next + d_rank); count = 2; }
-            else { e = 2 * (q_next + n2_whole + (s_rank >> 1)) + (s_rank & 1); count = 1; }
-            const int new_half = (fresh_singles & 1) ? next_units - 1 : -1;
-            if (n_buf < 2 && (e >> 1) < n_units) {
-                int pix; uint32_t smp; locate(e, pix, smp);
-                const int px = tx0 + (pix & 7), py = ty0 + (pix >> 3);
-                const bool inside = px < P.width && py < P.height;
-                const Rng4 c = rng_block((uint32_t)(py * P.width + px), smp >> 1, RT_TAG_CAMERA, P.seed_lo, P.seed_hi);
-                const bool odd = e & 1;
-                const f3 d_first = pinhole_dir((float)px + (odd ? c.z : c.x), (float)py + (odd ? c.w : c.y), inside && (int)smp >= s_lo && (int)smp < s_hi);
-                if (n_buf == 0) {
-                    b0d = d_first; b0q = e; n_buf = 1;
-                    if (count == 2) {                                      // whole unit: even sample first, odd sample behind it
-                        b1d = pinhole_dir((float)px + c.z, (float)py + c.w, inside && (int)smp + 1 >= s_lo && (int)smp + 1 < s_hi); b1q = e + 1; n_buf = 2;
-                    }
-                } else { b1d = d_first; b1q = e; n_buf = 2; }
-            }
-            q_next = next_units < n_units ? next_units : n_units;
-            half_unit = (new_half >= 0 && new_half < n_units) ? new_half : -1;
+        if (q_next < n_paths && __builtin_amdgcn_ballot_w64(starving) != 0) {
+            int q;
+            if (hand_out(n_buf == 0, q)) { primary(q, b0o, b0d); b0q = q; n_buf = 1; }
+            if (hand_out(n_buf == 1, q)) { primary(q, b1o, b1d); b1q = q; n_buf = 2; }
         }
         if (!alive && n_buf > 0) {
             locate(b0q, cur_pix, s_cur); --n_buf;
             pixel = (uint32_t)((ty0 + (cur_pix >> 3)) * P.width + tx0 + (cur_pix & 7));
-            if (RG) cur_pix |= (int)(threadIdx.x >> 6) << 6;              // the path remembers whose tile it belongs to
             rd = b0d; b0d = b1d; b0q = b1q;
             if (LENS) { ro = b0o; b0o = b1o; } else ro = f3mk(cam.origin[0], cam.origin[1], cam.origin[2]);
             T = f3mk(1, 1, 1);
             depth = 0; src = -1; pend = 0.0f;
             alive = rd.x != 0.0f || rd.y != 0.0f || rd.z != 0.0f;          // a pixel outside the image: nothing to trace
         }
-        // (a buffered ray may be void -- a pixel outside the image, the half of a unit outside the sample range: a wave whose lanes
-        // all drew one goes on while rays are buffered)
-        if (RG) { if (!__syncthreads_or((alive || n_buf > 0) ? 1 : 0)) break; }   // the workgroup stays together: its waves exchange paths
-        else if (__builtin_amdgcn_ballot_w64(alive || n_buf > 0) == 0) break;
+        // (a buffered ray may be void -- a pixel outside the image: a wave whose lanes all drew one goes on while rays are buffered)
+        if (__builtin_amdgcn_ballot_w64(alive || n_buf > 0) == 0) break;
         ++iters;
         SmallHit h; h.t = 0.0f; h.leaf = -1;
         if (alive) {
@@ -487,36 +410,6 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RT_SMA
                 pend = 0.0f;
             }
         }
-#if RT_SMALL_REGROUP
-        if (RG) {
-            const int wave = threadIdx.x >> 6;
-            int cls = 3;                                                   // 0 lambertian, 1 glass, 2 metal, 3 nothing to shade (miss, lamp, idle lane)
-            if (alive && h.leaf >= 0) { const uint32_t mt = lds_shade[h.leaf].meta & 0xff; cls = mt == RTC_MAT_LAMBERTIAN ? 0 : (mt == RTC_MAT_DIELECTRIC ? 1 : (mt == RTC_MAT_METAL ? 2 : 3)); }
-            const unsigned long long m0 = __builtin_amdgcn_ballot_w64(cls == 0), m1 = __builtin_amdgcn_ballot_w64(cls == 1), m2 = __builtin_amdgcn_ballot_w64(cls == 2);
-            const unsigned long long m3 = ~(m0 | m1 | m2);
-            const unsigned long long mine = cls == 0 ? m0 : (cls == 1 ? m1 : (cls == 2 ? m2 : m3));
-            int dest = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mine >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mine, 0u));
-            if (lane == 0) { xcnt[wave][0] = (int)__builtin_popcountll(m0); xcnt[wave][1] = (int)__builtin_popcountll(m1); xcnt[wave][2] = (int)__builtin_popcountll(m2); xcnt[wave][3] = (int)__builtin_popcountll(m3); }
-            __syncthreads();
-#pragma unroll
-            for (int c = 0; c < 4; ++c)
-#pragma unroll
-                for (int w = 0; w < 4; ++w) { const int n = xcnt[w][c]; dest += (c < cls || (c == cls && w < wave)) ? n : 0; }
-            dest = (dest + 64 * (int)(iters & 3u)) & 255;                  // rotate: the idle class must not always land in the same wave (it drains that wave's tile)
-            const f3 pp = ro + rd * h.t;                                   // the hit point travels instead of origin and t (h.t = 0 on a miss)
-            const int st_a = (alive ? 1 : 0) | (depth << 1), st_b = ((src + 1) & 0xff) | (((h.leaf + 1) & 0xff) << 8) | ((cur_pix & 0xff) << 16);
-            xbuf[3 * dest] = make_float4(pp.x, pp.y, pp.z, rd.x);
-            xbuf[3 * dest + 1] = make_float4(rd.y, rd.z, T.x, T.y);
-            xbuf[3 * dest + 2] = make_float4(T.z, __uint_as_float(s_cur), __int_as_float(st_a), __int_as_float(st_b));
-            __syncthreads();
-            const float4 r0 = xbuf[3 * threadIdx.x], r1 = xbuf[3 * threadIdx.x + 1], r2 = xbuf[3 * threadIdx.x + 2];
-            ro = f3mk(r0.x, r0.y, r0.z); rd = f3mk(r0.w, r1.x, r1.y); T = f3mk(r1.z, r1.w, r2.x);
-            s_cur = __float_as_uint(r2.y);
-            const int ga = __float_as_int(r2.z), gb = __float_as_int(r2.w);
-            alive = ga & 1; depth = ga >> 1; src = (gb & 0xff) - 1; h.leaf = ((gb >> 8) & 0xff) - 1; h.t = 0.0f; cur_pix = (gb >> 16) & 0xff;
-            pixel = (uint32_t)((xtile[cur_pix >> 6][1] + ((cur_pix & 63) >> 3)) * P.width + xtile[cur_pix >> 6][0] + (cur_pix & 7));
-        }
-#endif
         if (alive) {
             bool done;
             f3 L = f3mk(0, 0, 0);   // a path collects radiance once, where it ends (emitter or background): nothing to carry between bounces
@@ -605,10 +498,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RT_SMA
                 alive = false;
                 const bool finite = (fabsf(L.x) < 3.0e38f) && (fabsf(L.y) < 3.0e38f) && (fabsf(L.z) < 3.0e38f);
                 // (most paths of a scene with a black background end with nothing to add: no LDS traffic for those)
-                // (regrouping A/B: the sums of the path's HOME wave; additions of different waves to one address are not ordered there)
-                float *const sums = RG ? lds_sum[cur_pix >> 6] : tile_sum;
-                const int sp = RG ? (cur_pix & 63) : cur_pix;
-                if (finite && (L.x != 0.0f || L.y != 0.0f || L.z != 0.0f)) { atomicAdd(&sums[sp], L.x); atomicAdd(&sums[64 + sp], L.y); atomicAdd(&sums[128 + sp], L.z); }
+                if (finite && (L.x != 0.0f || L.y != 0.0f || L.z != 0.0f)) { atomicAdd(&tile_sum[cur_pix], L.x); atomicAdd(&tile_sum[64 + cur_pix], L.y); atomicAdd(&tile_sum[128 + cur_pix], L.z); }
             }
         }
     }
@@ -617,7 +507,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RT_SMA
     for (int off = 32; off > 0; off >>= 1) total += __shfl_xor(total, off, 64);
     if (PROBE) { if (lane == 0) tile_cost[tile] = (int)total; return; }   // cost probe: rays of this tile, nothing else is written
     const int px = tx0 + (lane & 7), py = ty0 + (lane >> 3);
-    if (px < P.width && py < P.height && !idle_wave) {                     // lane l writes pixel l of the tile
+    if (px < P.width && py < P.height) {                     // lane l writes pixel l of the tile
         const size_t pix_id = (size_t)py * P.width + px;
         const f3 sum = f3mk(tile_sum[lane], tile_sum[64 + lane], tile_sum[128 + lane]);
         if (log2_chunks == 0) {                                            // the only wave of this pixel: straight into the accumulator
@@ -626,7 +516,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RT_SMA
             accum[pix_id] = a;
         } else partial[(size_t)chunk * ((size_t)P.width * P.height) + pix_id] = make_float4(sum.x, sum.y, sum.z, (float)(s_hi - s_lo));
     }
-    if (lane == 0) { atomicAdd(counters, (unsigned long long)total); atomicAdd(counters + 1, (unsigned long long)(RG && idle_wave ? 0u : iters)); }
+    if (lane == 0) { atomicAdd(counters, (unsigned long long)total); atomicAdd(counters + 1, (unsigned long long)iters); }
 }
 
 // accum += the partial sums of a pixel's chunks, in chunk order: the result does not depend on which wave finished first
@@ -686,7 +576,7 @@ static void launch_small(const SmallScene &ss, const SceneT<float> &sc, const Ca
     const unsigned blocks = (unsigned)((((long long)p.n_tiles << log2_chunks) + 3) / 4);
 #define RT_SMALL_LAUNCH(I, L) hipLaunchKernelGGL((k_pathtrace_small<I, L, PROBE, false>), dim3(blocks), dim3(256), 0, stream, ss, sc, cam, p, accum, counters, perm, cost, partial, log2_chunks)
     const bool lens = cam.lens_radius > 0.0f;
-    if (p.integrator == 0 && ss.fused_lights && !RT_SMALL_REGROUP) {
+    if (p.integrator == 0 && ss.fused_lights) {
         if (lens) hipLaunchKernelGGL((k_pathtrace_small<0, true, PROBE, true>), dim3(blocks), dim3(256), 0, stream, ss, sc, cam, p, accum, counters, perm, cost, partial, log2_chunks);
         else hipLaunchKernelGGL((k_pathtrace_small<0, false, PROBE, true>), dim3(blocks), dim3(256), 0, stream, ss, sc, cam, p, accum, counters, perm, cost, partial, log2_chunks);
     }

@@ -11,6 +11,8 @@ static int g_repeat = 1;   // calibration mode: the kernel body is run g_repeat 
 
 template <int OP> __global__ void __launch_bounds__(256) k(float *out, float seed, int repeat) {
     float a[8]; uint32_t u[8]; uint64_t w[8];
+    if (OP == 21 && (threadIdx.x & 63) >= 32) return;   // half-empty waves: does the VALU skip the inactive half?
+    if (OP == 22 && (threadIdx.x & 63) >= 16) return;   // a quarter
     for (int i = 0; i < 8; i++) { a[i] = seed + threadIdx.x + i; u[i] = (uint32_t)(threadIdx.x * 2654435761u + i); w[i] = u[i]; }
     for (int it = 0; it < ITERS * repeat; ++it) {
 #pragma unroll
@@ -35,6 +37,7 @@ template <int OP> __global__ void __launch_bounds__(256) k(float *out, float see
             if (OP == 18) { asm volatile("v_xor_b32_e32 %0, %1, %0" : "+v"(u[i]) : "v"(u[(i + 1) & 7])); }
             if (OP == 19) { asm volatile("v_add_f32_e32 %0, %1, %0" : "+v"(a[i]) : "v"(seed)); }
             if (OP == 20) { asm volatile("v_and_or_b32 %0, %0, %1, %1" : "+v"(u[i]) : "v"(u[(i + 1) & 7])); }                 // VOP3 integer
+            if (OP == 21 || OP == 22) { asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(seed), "v"(a[(i + 1) & 7])); }
             if (OP == 10) { asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(seed), "v"(a[(i + 1) & 7])); }   // one FMA per lane: never packed
         }
     }
@@ -69,6 +72,7 @@ int main(int argc, char **argv) {
         run<11>("v_fmac_f32_e32", 1); run<10>("v_fma_f32 (cross operand)", 1); run<17>("v_fma_f32 (own chain)", 1); run<12>("v_mul_f32_e32", 1); run<13>("v_mul_f32_e64", 1);
         run<19>("v_add_f32_e32", 1); run<14>("v_mov_b32_e32", 1); run<15>("v_cndmask_b32_e32", 1); run<16>("v_max_f32_e32", 1); run<18>("v_xor_b32_e32", 1); run<20>("v_and_or_b32", 1);
         run<4>("v_mad_u64_u32", 1); run<1>("v_rcp_f32", 1);
+        run<21>("v_fma_f32, lanes 0-31 only", 1); run<22>("v_fma_f32, lanes 0-15 only", 1);
         return 0;
     }
     run<0>("v_fma_f32", 1); run<1>("v_rcp_f32", 1); run<2>("v_sqrt_f32", 1); run<3>("v_sin_f32", 1);

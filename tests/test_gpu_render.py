@@ -370,6 +370,10 @@ def test_small_scene_kernel_lights_on_every_axis(gpu):
     sc = gpu.Scene(world, lights, (0, 0, 0))
     cam = gpu.Camera((278, 278, -800), (278, 278, 0), (0, 1, 0), 40.0, 1.0, 0.0, 10.0)
     try:
+        # both lamps are loose rects of the pack: the small kernel takes their pdfs from the next ray's intersection (FUSED variant),
+        # so this test is also the YZ / XY coverage of that path
+        info = sc.small_info()
+        assert info["fused"] == 1 and info["fused_rects"] == 2 and info["fused_spheres"] == 0
         a, sa = sc.render(cam, gpu.Settings(96, 96, 4096, 10, 0, seed=1, kernel=1))
         b, sb = sc.render(cam, gpu.Settings(96, 96, 4096, 10, 0, seed=2, kernel=2))
         # the same image without importance sampling (cosine law only: neither the light pdf nor the light sampling is used) and

@@ -90,7 +90,8 @@ def test_c_abi_multi_device_render_equals_one_device(gpu):
     reassociation, sample counts exact, the call adds to what the host buffer held; the same handle twice is refused."""
     import ctypes as C
     L = gpu.lib()
-    for name, W, H, spp in (("cornell", 240, 135, 70), ("book1", 160, 90, 20)):
+    # (the last case is BASELINE config 4's image size: 3840 x 2160, a few samples of its 16,384)
+    for name, W, H, spp in (("cornell", 240, 135, 70), ("book1", 160, 90, 20), ("cornell", 3840, 2160, 7)):
         sc, cam, view = gpu.build_named_scene(name, aspect=W / H)
         clones = []
         try:

@@ -188,10 +188,18 @@ def main():
         if world == 1 and a.gpus > 1:
             sys.exit(f"--gpus {a.gpus} needs one process per GPU: launch with python -m torch.distributed.run --nproc-per-node {a.gpus}")
         a.gpus = world
+    # Test hooks (tests/test_gpu_dist.py runs the N > 1 path of this file on a one-GPU box): RTC_BENCH_ONE_DEVICE=1 puts every rank on
+    # cuda:0, RTC_BENCH_BACKEND=gloo replaces RCCL (which wants one GPU per rank).  Neither is set by the driver.
+    if os.environ.get("RTC_BENCH_ONE_DEVICE") == "1":
+        local_rank = 0
+    backend = os.environ.get("RTC_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     ra.rtc_init()                                                # raises without a gfx950 GPU: there is no CPU fallback
 
     cornell = a.scene == "cornell"
@@ -201,15 +209,25 @@ def main():
     rgb8 = torch.empty((HEIGHT, WIDTH, 3), dtype=torch.uint8, device=dev)
     kernel_ms, rays_total, kernel_used, lane_fill = [], 0, [0], [0.0]
 
+    def tonemap(acc, frame):                                     # rank 0 holds the frame's sum over all ranks
+        if rank == 0:
+            rc = ra.lib().rtc_tonemap_u8_device(acc.data_ptr(), WIDTH, HEIGHT, rgb8.data_ptr(), torch.cuda.current_stream(dev).cuda_stream)
+            assert rc == 0
+
+    # N > 1: two accumulators, so that the reduce of frame i (RCCL's stream) overlaps the render of frame i + 1; every frame's
+    # reduce and tonemap still happen inside the timed region (the fence flushes the pipeline).  N = 1: nothing to overlap.
+    pipe = rdist.FramePipeline(HEIGHT, WIDTH, dev, on_frame=tonemap) if world > 1 else None
+
     def step(i, record):
         nonlocal rays_total
         begin, end = rdist.shard_samples(a.spp * world, rank, world, base=i * a.spp * world)
-        accum.zero_()
-        stream = rdist.render_into(scene, cam, ra.Settings(WIDTH, HEIGHT, 0, depth, view.integrator, seed=0, sample_begin=begin, sample_end=end), accum)
-        rdist.reduce_accum(accum, dst=0)                         # one collective per frame (RCCL over xGMI); no-op at N=1
-        if rank == 0:
-            rc = ra.lib().rtc_tonemap_u8_device(accum.data_ptr(), WIDTH, HEIGHT, rgb8.data_ptr(), stream)
-            assert rc == 0
+        settings = ra.Settings(WIDTH, HEIGHT, 0, depth, view.integrator, seed=0, sample_begin=begin, sample_end=end)
+        if pipe is not None:
+            stream = pipe.submit(lambda acc: rdist.render_into(scene, cam, settings, acc))   # one collective per frame (RCCL over xGMI)
+        else:
+            accum.zero_()
+            stream = rdist.render_into(scene, cam, settings, accum)
+            tonemap(accum, i)
         # Reading the counters waits for the render kernel's end event (a host sync).  At N = 1 that is every step -- the
         # roofline's kernel time is the average over the timed launches; at N > 1 a sync per step would stop rank r from
         # enqueueing its next render while the reduce of this one is in flight, so only the last timed step is read.
@@ -220,6 +238,8 @@ def main():
             kernel_used[0], lane_fill[0] = st["kernel_used"], st["lane_fill"]
 
     def fence():
+        if pipe is not None:
+            pipe.flush()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()

@@ -133,3 +133,24 @@ def test_cli_multi_gpu_flag(gpu, tmp_path):
         assert open(a, "rb").read() == open(b, "rb").read()
     too_many = subprocess.run(common + ["-o", b, "-g", str(n + 1)], capture_output=True, timeout=120)
     assert too_many.returncode != 0 and b"device(s)" in too_many.stderr
+
+
+def test_bench_two_ranks_on_one_gpu(gpu):
+    """bench.py's N > 1 path end to end (torch.distributed.run, two ranks, the frame pipeline with its overlapped reduce, the
+    max-over-ranks timing, rank 0's JSON line) on the one GPU of a test box: both ranks on cuda:0, gloo instead of RCCL (test
+    hooks of bench.py).  Checks the line's bookkeeping, not the speed."""
+    import json
+    env = dict(os.environ, RTC_BENCH_ONE_DEVICE="1", RTC_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    port = str(29900 + os.getpid() % 90)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", port,
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--width", "480", "--height", "270", "--spp", "32"]
+    p = subprocess.run(cmd, capture_output=True, timeout=400, env=env, cwd=ROOT)
+    assert p.returncode == 0, p.stderr.decode()[-3000:]
+    lines = [l for l in p.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 3 and line["scaling"] == "weak"
+    assert line["config"]["global_spp"] == 64 and line["config"]["spp_per_gpu"] == 32
+    samples = 480 * 270 * 64 * 3
+    assert abs(line["value"] * 1e6 * line["ms_per_step"] * 1e-3 * 3 - samples) <= 1e-6 * samples
+    assert 2.5 < line["rays_per_sample"] < 4.0 and "cpu_baseline" not in line and "other_configs" not in line

@@ -72,21 +72,27 @@ static int extend(int v, int n) { return n && v < (1 << (n - 1)) ? v - (1 << n) 
 
 /* One 8-point pass of the IJG islow IDCT on s[0], s[st], ..., s[7 st]; constants = round(c * 4096).  Outputs the even part
  * x[0..3] and the odd part t[0..3] scaled by 4096: the caller adds its rounding bias to x and forms x[k] +- t[3 - k]. */
+/* (All sums and products wrap modulo 2^32 -- unsigned arithmetic, read back as int -- so that a corrupt file's out-of-range
+ * coefficients give the values two's-complement hardware gives the reference's int arithmetic instead of undefined behaviour;
+ * for coefficients a valid file can hold nothing overflows.) */
+typedef unsigned int u32;
 static void idct_1d(const int *s, int st, int x[4], int t[4]) {
-    int p2 = s[2 * st], p3 = s[6 * st];
-    int p1 = (p2 + p3) * 2217;
-    const int e2 = p1 + p3 * -7567, e3 = p1 + p2 * 3135;
-    p2 = s[0]; p3 = s[4 * st];
-    const int e0 = (p2 + p3) * 4096, e1 = (p2 - p3) * 4096;
-    x[0] = e0 + e3; x[3] = e0 - e3; x[1] = e1 + e2; x[2] = e1 - e2;
-    int t0 = s[7 * st], t1 = s[5 * st], t2 = s[3 * st], t3 = s[st];
-    p3 = t0 + t2; int p4 = t1 + t3; p1 = t0 + t3; p2 = t1 + t2;
-    const int p5 = (p3 + p4) * 4816;
-    t0 *= 1223; t1 *= 8410; t2 *= 12586; t3 *= 6149;
-    p1 = p5 + p1 * -3685; p2 = p5 + p2 * -10497; p3 *= -8034; p4 *= -1597;
-    t[3] = t3 + p1 + p4; t[2] = t2 + p2 + p3; t[1] = t1 + p2 + p4; t[0] = t0 + p1 + p3;
+    u32 p2 = (u32)s[2 * st], p3 = (u32)s[6 * st];
+    u32 p1 = (p2 + p3) * 2217u;
+    const u32 e2 = p1 + p3 * (u32)-7567, e3 = p1 + p2 * 3135u;
+    p2 = (u32)s[0]; p3 = (u32)s[4 * st];
+    const u32 e0 = (p2 + p3) * 4096u, e1 = (p2 - p3) * 4096u;
+    x[0] = (int)(e0 + e3); x[3] = (int)(e0 - e3); x[1] = (int)(e1 + e2); x[2] = (int)(e1 - e2);
+    u32 t0 = (u32)s[7 * st], t1 = (u32)s[5 * st], t2 = (u32)s[3 * st], t3 = (u32)s[st];
+    p3 = t0 + t2; u32 p4 = t1 + t3; p1 = t0 + t3; p2 = t1 + t2;
+    const u32 p5 = (p3 + p4) * 4816u;
+    t0 *= 1223u; t1 *= 8410u; t2 *= 12586u; t3 *= 6149u;
+    p1 = p5 + p1 * (u32)-3685; p2 = p5 + p2 * (u32)-10497; p3 *= (u32)-8034; p4 *= (u32)-1597;
+    t[3] = (int)(t3 + p1 + p4); t[2] = (int)(t2 + p2 + p3); t[1] = (int)(t1 + p2 + p4); t[0] = (int)(t0 + p1 + p3);
 }
 static unsigned char clamp8(int v) { return (unsigned char)(v < 0 ? 0 : (v > 255 ? 255 : v)); }
+static int wsum(int a, int b) { return (int)((u32)a + (u32)b); }
+static int wdif(int a, int b) { return (int)((u32)a - (u32)b); }
 static void idct_block(const short *coef, unsigned char *out, int stride) {
     int val[64];
     for (int c = 0; c < 8; c++) {                                      /* columns; 2 extra bits kept */
@@ -99,13 +105,13 @@ static void idct_block(const short *coef, unsigned char *out, int stride) {
         int in[8], x[4], t[4];
         for (int k = 0; k < 8; k++) in[k] = d[8 * k];
         idct_1d(in, 1, x, t);
-        for (int k = 0; k < 4; k++) { x[k] += 512; v[8 * k] = (x[k] + t[3 - k]) >> 10; v[8 * (7 - k)] = (x[k] - t[3 - k]) >> 10; }
+        for (int k = 0; k < 4; k++) { x[k] = wsum(x[k], 512); v[8 * k] = wsum(x[k], t[3 - k]) >> 10; v[8 * (7 - k)] = wdif(x[k], t[3 - k]) >> 10; }
     }
     for (int r = 0; r < 8; r++) {                                      /* rows: 12 + 2 + 3 bits to drop, level shift +128 folded in */
         int x[4], t[4];
         idct_1d(val + 8 * r, 1, x, t);
         unsigned char *o = out + (size_t)r * stride;
-        for (int k = 0; k < 4; k++) { x[k] += 65536 + (128 << 17); o[k] = clamp8((x[k] + t[3 - k]) >> 17); o[7 - k] = clamp8((x[k] - t[3 - k]) >> 17); }
+        for (int k = 0; k < 4; k++) { x[k] = wsum(x[k], 65536 + (128 << 17)); o[k] = clamp8(wsum(x[k], t[3 - k]) >> 17); o[7 - k] = clamp8(wdif(x[k], t[3 - k]) >> 17); }
     }
 }
 

@@ -283,3 +283,29 @@ def test_lights_that_are_leaves_of_the_small_pack(monkeypatch):
     sc, cam, view = A.build_named_scene("cornell", host_only=True)
     info = sc.small_info(); sc.close()
     assert info["fused"] == 0 and info["fused_rects"] == 0 and info["fused_spheres"] == 0
+
+
+def test_jpeg_decoder_under_sanitizers(tmp_path):
+    """tools/fuzz/jpeg_fuzz.c: 1,500 mutations of the earth map and of a 4:2:0 / restart-interval case (byte flips, truncations,
+    stray markers) through rt_jpeg_decode compiled with ASan + UBSan: no over-read, no undefined arithmetic (the IDCT wraps like
+    the reference's int arithmetic does on two's-complement hardware), every success returns a full image."""
+    import shutil
+    import subprocess
+    if not shutil.which("gcc"):
+        pytest.skip("no gcc")
+    host = os.path.join(ROOT, "raytracer_amd", "csrc", "host")
+    exe = tmp_path / "jpeg_fuzz"
+    r = subprocess.run(["gcc", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-static-libasan", "-I" + os.path.join(ROOT, "include"), "-I" + host,
+                        os.path.join(ROOT, "tools", "fuzz", "jpeg_fuzz.c"), os.path.join(host, "jpeg_decode.c"), "-lm", "-o", str(exe)], capture_output=True, text=True)
+    if r.returncode != 0 and ("asan" in r.stderr.lower() or "ubsan" in r.stderr.lower()):
+        pytest.skip("no sanitizer runtime in this image")
+    assert r.returncode == 0, r.stderr[-2000:]
+    cases = np.load(os.path.join(ROOT, "tests", "golden", "jpeg_cases.npz"))
+    names = sorted(k[:-len("_jpg")] for k in cases.files if k.endswith("_jpg"))
+    pick = [n for n in names if "420" in n][:1] or names[:1]
+    small = tmp_path / "case.jpg"
+    small.write_bytes(cases[pick[0] + "_jpg"].tobytes())
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:verify_asan_link_order=0")
+    for path, n in ((os.path.join(ROOT, "tests", "golden", "earthmap.jpg"), "500"), (str(small), "1000")):
+        run = subprocess.run([str(exe), path, n], capture_output=True, text=True, env=env, timeout=600)
+        assert run.returncode == 0 and "decoded" in run.stdout and "runtime error" not in run.stderr, (run.stdout[-500:], run.stderr[-2000:])

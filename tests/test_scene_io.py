@@ -206,3 +206,37 @@ print("accepted", acc, "refused", ref)
     assert out.returncode == 0 and b"accepted" in out.stdout, out.stderr.decode()[-2000:]
     acc, ref = int(out.stdout.split()[1]), int(out.stdout.split()[3])
     assert acc + ref == 480 and ref > 0
+
+
+def test_scene_loader_mutation_fuzz_under_sanitizers(tmp_path):
+    """tools/fuzz/scene_fuzz.cpp: random payload words of valid scene files overwritten (small integers, sign bits, huge values), the CRC
+    brought up to date so that the damage reaches validate_flat_scene, and whatever loads walked by the host code that runs after
+    a load (four-child tree, light matching) -- compiled with ASan + UBSan.  A gap in the validator shows up as an out-of-bounds read."""
+    import shutil
+    import subprocess
+    if not shutil.which("g++"):
+        pytest.skip("no g++")
+    import raytracer_amd.api as A
+    from conftest import ROOT
+    host = os.path.join(ROOT, "raytracer_amd", "csrc", "host")
+    inc = ["-I" + os.path.join(ROOT, "include"), "-I" + host, "-I" + os.path.join(ROOT, "raytracer_amd", "csrc")]
+    san = ["-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined"]
+    objs = []
+    for src in ("scene_api.c", "jpeg_decode.c"):
+        o = str(tmp_path / (src + ".o"))
+        r = subprocess.run(["gcc"] + san + ["-c"] + inc + [os.path.join(host, src), "-o", o], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-2000:]
+        objs.append(o)
+    exe = str(tmp_path / "scene_fuzz")
+    r = subprocess.run(["g++", "-std=c++17"] + san + ["-static-libasan"] + inc + [os.path.join(ROOT, "tools", "fuzz", "scene_fuzz.cpp"), os.path.join(host, "scene_io.cpp"),
+                        os.path.join(host, "flatten.cpp")] + objs + ["-lz", "-lpthread", "-lm", "-o", exe], capture_output=True, text=True)
+    if r.returncode != 0 and ("asan" in r.stderr.lower() or "ubsan" in r.stderr.lower()):
+        pytest.skip("no sanitizer runtime in this image")
+    assert r.returncode == 0, r.stderr[-2000:]
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0:verify_asan_link_order=0")
+    for name in ("cornell", "cornell_smoke", "book1"):
+        sc, cam, view = A.build_named_scene(name, host_only=True)
+        path = str(tmp_path / (name + ".rtcscene"))
+        sc.save(path); sc.close()
+        run = subprocess.run([exe, path, "400", str(tmp_path / "mutated.rtcscene")], capture_output=True, text=True, env=env, timeout=900)
+        assert run.returncode == 0 and "loaded" in run.stdout and "runtime error" not in run.stderr, (run.stdout[-300:], run.stderr[-2500:])

@@ -30,6 +30,10 @@ static void reg_push(registry *r, void *p) {
     r->v[r->n++] = p;
 }
 static registry g_textures, g_materials, g_lists;
+/* Bumped by every constructor and every free: ray_color (rtc_api.cpp) keeps the device tables of the last scene it was handed and must
+ * not trust a (world, lights) pointer pair whose lists have been freed and rebuilt at the same addresses in between. */
+static unsigned long long g_generation;
+unsigned long long rt_api_generation(void) { return g_generation; }
 
 /* ---- utils.h:21-26 -------------------------------------------------------------------------- */
 double random_double(void) { return rand() / (RAND_MAX + 1.0); }
@@ -38,7 +42,7 @@ int random_int(int min, int max) { return (int)random_double_scaled(min, max + 1
 double deg2rad(double deg) { return deg * PI / 180.0; }
 
 /* ---- textures ------------------------------------------------------------------------------- */
-static texture *tex_alloc(rt_tex_kind kind) {
+static texture *tex_alloc(rt_tex_kind kind) { ++g_generation;
     texture *t = (texture *)calloc(1, sizeof *t);
     t->kind = kind; t->id = g_textures.n; reg_push(&g_textures, t); return t;
 }
@@ -113,18 +117,18 @@ texture *texture_image_init(char *filename) {
 }
 /* texture.c:76-90 frees one texture and leaves its pointer in the registry (a later textures_free_all would free it twice);
  * here the slot is cleared.  A checker does not own its two sub-textures: they are registered on their own. */
-void texture_free(texture *t) {
+void texture_free(texture *t) { ++g_generation;
     if (!t) return;
     if (t->id >= 0 && t->id < g_textures.n && g_textures.v[t->id] == t) g_textures.v[t->id] = NULL;
     free(t->ranvec); free(t->perm); free(t->pixels); free(t);
 }
-void textures_free_all(void) {
+void textures_free_all(void) { ++g_generation;
     for (int i = 0; i < g_textures.n; i++) { texture *t = (texture *)g_textures.v[i]; if (!t) continue; free(t->ranvec); free(t->perm); free(t->pixels); free(t); }
     g_textures.n = 0;
 }
 
 /* ---- materials ------------------------------------------------------------------------------ */
-static material *mat_alloc(rt_mat_kind kind) {
+static material *mat_alloc(rt_mat_kind kind) { ++g_generation;
     material *m = (material *)calloc(1, sizeof *m); m->kind = kind; m->id = g_materials.n; reg_push(&g_materials, m); return m;
 }
 material *material_lambertian_new(texture *t) { material *m = mat_alloc(RT_MAT_LAMBERTIAN); m->tex = t; return m; }
@@ -136,21 +140,21 @@ material *material_light_new_from_color(color c) { return material_light_new(tex
 material *material_isotropic_new(texture *t) { material *m = mat_alloc(RT_MAT_ISOTROPIC); m->tex = t; return m; }
 material *material_isotropic_new_from_color(color c) { return material_isotropic_new(texture_solid_color_init(c)); }
 /* material.c:26-33: one material (its texture stays with the texture registry); the registry slot is cleared */
-void material_free(material *m) {
+void material_free(material *m) { ++g_generation;
     if (!m) return;
     if (m->id >= 0 && m->id < g_materials.n && g_materials.v[m->id] == m) g_materials.v[m->id] = NULL;
     free(m);
 }
-void materials_free_all(void) { for (int i = 0; i < g_materials.n; i++) free(g_materials.v[i]); g_materials.n = 0; }
+void materials_free_all(void) { ++g_generation; for (int i = 0; i < g_materials.n; i++) free(g_materials.v[i]); g_materials.n = 0; }
 
 /* ---- lists ---------------------------------------------------------------------------------- */
-hittable_list *hittable_list_new(int max_size) {
+hittable_list *hittable_list_new(int max_size) { ++g_generation;
     hittable_list *l = (hittable_list *)calloc(1, sizeof *l);
     l->size = max_size > 4 ? max_size : 4; l->objs = (hittable **)malloc(sizeof(hittable *) * (size_t)l->size); l->gc = 1;
     reg_push(&g_lists, l); return l;
 }
 hittable_list *hittable_list_new_no_gc(int max_size) { hittable_list *l = hittable_list_new(max_size); l->gc = 0; return l; }
-void hittable_list_add(hittable_list *l, hittable *o) {
+void hittable_list_add(hittable_list *l, hittable *o) { ++g_generation;
     if (l == NULL) return;
     if (l->index == l->size) { l->size *= 2; l->objs = (hittable **)realloc(l->objs, sizeof(hittable *) * (size_t)l->size); }
     l->objs[l->index++] = o;
@@ -162,7 +166,7 @@ static void list_free_members(hittable_list *l) {
     for (int i = 0; i < l->index; i++) hittable_free(l->objs[i]);
     l->index = 0;
 }
-void hittable_list_free(hittable_list *l) {
+void hittable_list_free(hittable_list *l) { ++g_generation;
     if (l == NULL) return;
     for (int i = 0; i < g_lists.n; i++) if (g_lists.v[i] == l) g_lists.v[i] = NULL;   /* hittable_lists_free_all must not see it again */
     list_free_members(l);
@@ -171,14 +175,14 @@ void hittable_list_free(hittable_list *l) {
 /* Members first, the lists themselves afterwards: a BVH node reads its source list while it is freed (hittable_free),
  * and that list may have been registered -- and so would have been freed -- before the list that owns the node
  * (02 main.c:232-254: the box list exists before `objects`). */
-void hittable_lists_free_all(void) {
+void hittable_lists_free_all(void) { ++g_generation;
     for (int i = 0; i < g_lists.n; i++) if (g_lists.v[i]) list_free_members((hittable_list *)g_lists.v[i]);
     for (int i = 0; i < g_lists.n; i++) if (g_lists.v[i]) { hittable_list *l = (hittable_list *)g_lists.v[i]; free(l->objs); free(l); }
     g_lists.n = 0;
 }
 
 /* ---- hittables ------------------------------------------------------------------------------ */
-static hittable *hit_alloc(hittable_list *world, rt_hit_kind kind) {
+static hittable *hit_alloc(hittable_list *world, rt_hit_kind kind) { ++g_generation;
     hittable *h = (hittable *)calloc(1, sizeof *h); h->kind = kind; hittable_list_add(world, h); return h;
 }
 hittable *hittable_sphere_new(hittable_list *world, point3 center, double r, material *mat) {
@@ -256,7 +260,7 @@ hittable *bvh_node_init(hittable_list *world, hittable_list *objects, double t0,
     if (objects->index > 0) bvh_visit_order(objects, 0, objects->index, h->bvh_order, &h->bvh_count);
     return h;
 }
-void hittable_free(hittable *o) { /* ownership as hittable.c:336-366; a BVH owns the members of its (no-gc) source list */
+void hittable_free(hittable *o) { ++g_generation; /* ownership as hittable.c:336-366; a BVH owns the members of its (no-gc) source list */
     switch (o->kind) {
     case RT_H_BVH: for (int i = 0; i < o->members->index; i++) hittable_free(o->members->objs[i]); o->members->index = 0; free(o->bvh_order); break;
     case RT_H_TRANSLATE: case RT_H_ROTATE: case RT_H_FLIP: case RT_H_MEDIUM: hittable_free(o->child); break;

@@ -69,6 +69,8 @@ struct camera {
 
 int rt_bounding_box(const hittable *o, double t0, double t1, rt_box *out);
 /* jpeg_decode.c: baseline JPEG -> malloc'ed RGB8, rows top to bottom; 0 on malformed / unsupported input */
+/* changes whenever anything is constructed, added to a list or freed through the API (scene_api.c) */
+unsigned long long rt_api_generation(void);
 int rt_jpeg_decode(const unsigned char *data, size_t n, int *width, int *height, unsigned char **rgb_out);
 
 #ifdef __cplusplus

@@ -714,17 +714,18 @@ color ray_color(ray *r, color *background, hittable_list *world, hittable_list *
     static rtc_scene *cached = nullptr;
     static const hittable_list *c_world = nullptr, *c_lights = nullptr;
     static int c_nw = -1, c_nl = -1; static color c_bg = {0, 0, 0};
+    static unsigned long long c_gen = 0;   // scene_api.c: bumped by every constructor, list add and free -- a rebuilt scene at the same addresses is seen
     static unsigned long long calls = 0;
     const color black = {0, 0, 0};
     if (!r || !world) return black;
     std::lock_guard<std::mutex> lk(mu);
     const color bg = background ? *background : black;
     const int nw = hittable_list_index(world), nl = lights ? hittable_list_index(lights) : 0;
-    if (!cached || c_world != world || c_lights != lights || c_nw != nw || c_nl != nl || c_bg.x != bg.x || c_bg.y != bg.y || c_bg.z != bg.z) {
+    if (!cached || c_gen != rt_api_generation() || c_world != world || c_lights != lights || c_nw != nw || c_nl != nl || c_bg.x != bg.x || c_bg.y != bg.y || c_bg.z != bg.z) {
         if (cached) { rtc_scene_free(cached); cached = nullptr; }
         cached = rtc_scene_build(world, lights, &bg, 0.0, 1.0);
         if (!cached) { std::printf("!! ray_color: %s\n", rtc_last_error()); return black; }
-        c_world = world; c_lights = lights; c_nw = nw; c_nl = nl; c_bg = bg;
+        c_world = world; c_lights = lights; c_nw = nw; c_nl = nl; c_bg = bg; c_gen = rt_api_generation();
     }
     rtc_settings st; std::memset(&st, 0, sizeof st);
     st.width = st.height = 2; st.max_depth = recursion_depth; st.integrator = 0; st.mixture_light_weight = 0.1;   // ray.c:72

@@ -309,3 +309,46 @@ def test_jpeg_decoder_under_sanitizers(tmp_path):
     for path, n in ((os.path.join(ROOT, "tests", "golden", "earthmap.jpg"), "500"), (str(small), "1000")):
         run = subprocess.run([str(exe), path, n], capture_output=True, text=True, env=env, timeout=600)
         assert run.returncode == 0 and "decoded" in run.stdout and "runtime error" not in run.stderr, (run.stdout[-500:], run.stderr[-2000:])
+
+
+def test_installed_tree_builds_a_c_host(tmp_path):
+    """`make install PREFIX=...` (csrc/Makefile): a C host compiled against ONLY the installed headers, library and pkg-config file
+    builds the Cornell scene through the reference's constructors (03_FullTracer/main.c:34-63) and gets it flattened -- no GPU
+    call, so this runs on the CPU box; the installed rtc_render finds its library through its rpath."""
+    import shutil
+    import subprocess
+    if not shutil.which("gcc") or not os.path.exists(os.path.join(ROOT, "raytracer_amd", "librtc.so")):
+        pytest.skip("needs gcc and a built librtc.so")
+    prefix = tmp_path / "prefix"
+    r = subprocess.run(["make", "-C", os.path.join(ROOT, "raytracer_amd", "csrc"), "install", f"PREFIX={prefix}"], capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stderr[-2000:]
+    pc = dict(line.split(": ", 1) for line in (prefix / "lib" / "pkgconfig" / "raytracer_amd.pc").read_text().splitlines() if ": " in line)
+    subst = lambda s: s.replace("${libdir}", str(prefix / "lib")).replace("${includedir}", str(prefix / "include" / "raytracer_amd"))
+    src = tmp_path / "host.c"
+    src.write_text(r'''
+#include <stdio.h>
+#include <rtc.h>
+int main(void) {
+    hittable_list *world = hittable_list_new(16), *lights = hittable_list_new_no_gc(4);
+    material *white = material_lambertian_new_from_color((color){.73, .73, .73}), *light = material_light_new_from_color((color){15, 15, 15});
+    hittable_rect_new(world, 0, 555, 0, 555, 0, 0, 555, XZ, white);
+    hittable *l = hittable_flip_face_init(world, hittable_rect_new(NULL, 213, 343, 0, 0, 227, 332, 554, XZ, light));
+    hittable_list_add(lights, l);
+    hittable_box_new(world, (point3){0, 0, 0}, (point3){165, 330, 165}, white);
+    color bg = {0, 0, 0};
+    rtc_scene *s = rtc_scene_flatten_only(world, lights, &bg, 0, 1);
+    if (!s) { printf("flatten failed: %s\n", rtc_last_error()); return 1; }
+    printf("prims %d\n", rtc_scene_num_prims(s));
+    rtc_scene_free(s);
+    hittable_list_free(lights); hittable_list_free(world); materials_free_all(); textures_free_all();
+    return 0;
+}
+''')
+    exe = tmp_path / "host"
+    r = subprocess.run(["gcc", "-O1", str(src), "-o", str(exe)] + subst(pc["Cflags"]).split() + subst(pc["Libs"]).split(), capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    run = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert run.returncode == 0 and run.stdout.strip() == "prims 8", (run.stdout, run.stderr[-1000:])
+    ldd = subprocess.run(["ldd", str(prefix / "bin" / "rtc_render")], capture_output=True, text=True).stdout
+    found = [os.path.normpath(line.split("=>")[1].split("(")[0].strip()) for line in ldd.splitlines() if line.strip().startswith("librtc.so")]
+    assert found == [str(prefix / "lib" / "librtc.so")], ldd

@@ -193,9 +193,12 @@ def main():
     if os.environ.get("RTC_BENCH_ONE_DEVICE") == "1":
         local_rank = 0
     backend = os.environ.get("RTC_BENCH_BACKEND", "nccl")
+    # RTC_BENCH_FORCE_DIST=1 (test hook as well): one rank takes the N > 1 code path -- process group, frame pipeline, async reduce,
+    # all_reduce of the timings -- so that the RCCL calls themselves run on a one-GPU box
+    dist_on = world > 1 or os.environ.get("RTC_BENCH_FORCE_DIST") == "1"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    if dist_on:
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
@@ -216,7 +219,7 @@ def main():
 
     # N > 1: two accumulators, so that the reduce of frame i (RCCL's stream) overlaps the render of frame i + 1; every frame's
     # reduce and tonemap still happen inside the timed region (the fence flushes the pipeline).  N = 1: nothing to overlap.
-    pipe = rdist.FramePipeline(HEIGHT, WIDTH, dev, on_frame=tonemap) if world > 1 else None
+    pipe = rdist.FramePipeline(HEIGHT, WIDTH, dev, on_frame=tonemap) if dist_on else None
 
     def step(i, record):
         nonlocal rays_total
@@ -231,17 +234,17 @@ def main():
         # Reading the counters waits for the render kernel's end event (a host sync).  At N = 1 that is every step -- the
         # roofline's kernel time is the average over the timed launches; at N > 1 a sync per step would stop rank r from
         # enqueueing its next render while the reduce of this one is in flight, so only the last timed step is read.
-        if record and (world == 1 or i == a.warmup + a.steps - 1):
+        if record and (not dist_on or i == a.warmup + a.steps - 1):
             st = scene.stats(stream)
             kernel_ms.append(st["kernel_ms"])
-            rays_total += st["rays"] * (1 if world == 1 else a.steps)   # every step traces the same number of paths +- the sample range
+            rays_total += st["rays"] * (a.steps if dist_on else 1)   # every step traces the same number of paths +- the sample range
             kernel_used[0], lane_fill[0] = st["kernel_used"], st["lane_fill"]
 
     def fence():
         if pipe is not None:
             pipe.flush()
         torch.cuda.synchronize()
-        if world > 1:
+        if dist_on:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -255,7 +258,7 @@ def main():
     elapsed = time.perf_counter() - t0
 
     t = torch.tensor([elapsed, float(rays_total), float(np.mean(kernel_ms)) if kernel_ms else 0.0], dtype=torch.float64, device=dev)
-    if world > 1:
+    if dist_on:
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         tsum = t.clone()
@@ -306,7 +309,7 @@ def main():
             ra.png_write(a.png, rgb8.cpu().numpy())
         print(json.dumps(line), flush=True)
     scene.close()
-    if world > 1:
+    if dist_on:
         dist.barrier()
         dist.destroy_process_group()
 

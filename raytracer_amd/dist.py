@@ -28,7 +28,7 @@ def reduce_accum(accum, dst=0, group=None):
 def reduce_accum_async(accum, dst=0, group=None):
     """reduce_accum that returns at once: the collective runs on the backend's own stream behind the work already enqueued on
     the current one; the handle's wait() makes the current stream wait for it (None when there is nothing to reduce)."""
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    if dist.is_available() and dist.is_initialized():    # (a one-rank group too: the backend's own no-op, same call sequence)
         return dist.reduce(accum, dst=dst, op=dist.ReduceOp.SUM, group=group, async_op=True)
     return None
 

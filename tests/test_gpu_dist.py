@@ -154,3 +154,25 @@ def test_bench_two_ranks_on_one_gpu(gpu):
     samples = 480 * 270 * 64 * 3
     assert abs(line["value"] * 1e6 * line["ms_per_step"] * 1e-3 * 3 - samples) <= 1e-6 * samples
     assert 2.5 < line["rays_per_sample"] < 4.0 and "cpu_baseline" not in line and "other_configs" not in line
+
+
+@pytest.mark.gpu
+def test_bench_distributed_path_through_rccl_with_one_rank(gpu):
+    """The N > 1 code path of bench.py with the backend the driver uses -- RCCL ("nccl"): process group bound to the device, the
+    frame pipeline's async reduce and its wait(), barrier, float64 all_reduce of the timings -- on the one GPU of a test box, as a
+    one-rank group (RTC_BENCH_FORCE_DIST=1).  The two-rank test above covers the sharding with gloo; this one covers the calls
+    into RCCL that gloo replaces there."""
+    import json
+    env = dict(os.environ, RTC_BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    port = str(29800 + os.getpid() % 90)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", port,
+           os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--width", "480", "--height", "270", "--spp", "32", "--no-cpu", "--no-other"]
+    p = subprocess.run(cmd, capture_output=True, timeout=400, env=env, cwd=ROOT)
+    assert p.returncode == 0, p.stderr.decode()[-3000:]
+    lines = [l for l in p.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 1 and line["steps"] == 3
+    samples = 480 * 270 * 32 * 3
+    assert abs(line["value"] * 1e6 * line["ms_per_step"] * 1e-3 * 3 - samples) <= 1e-6 * samples
+    assert 2.5 < line["rays_per_sample"] < 4.0

@@ -199,6 +199,10 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if dist_on:
+        # RCCL's stream at high priority: when a render ends, the reduce of its frame and the next frame's render become ready together,
+        # and the render is a persistent kernel that fills every wave slot -- dispatched first it would hold the reduce back until its own
+        # tail.  Priority decides which is dispatched first (it cannot preempt running waves); the reduce needs a few dozen workgroups.
+        os.environ.setdefault("TORCH_NCCL_HIGH_PRIORITY", "1")
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:

@@ -95,6 +95,10 @@ int  rtc_scene_bvh_info(const rtc_scene *scene, long long *out4);
  * light pdfs fused into the intersection (every light-list entry is a world-space leaf of the pack), rects and spheres that
  * carry a light's pdf.  Inspection only; no reference counterpart. */
 int  rtc_scene_small_info(const rtc_scene *scene, int *out8);
+/* How the wavefront path intersects this scene's rays (BVH scenes; inspection, no reference counterpart): out4 = [0] 1 if the node and
+ * leaf tables are staged in LDS (small trees without media, at most 80 KB with the stacks; RTC_WF_LDS_TABLES=0 in the environment
+ * turns it off), [1] bytes of LDS per workgroup in that case, [2] inner nodes, [3] leaf records.  Needs device tables. */
+int  rtc_scene_extend_info(const rtc_scene *scene, int *out4);
 /* The production BVH itself, for structural checks on a machine without a GPU: nodes16 = per inner node 16 words (float
  * lo0[3], int child0, float hi0[3], int count0, the same for child 1; child < 0 encodes a leaf run ~((first << 3) | (count-1))),
  * leaves16 = per leaf slot 16 words (15 floats of world-space geometry + meta), prim_of_slot = primitive id per leaf slot.

@@ -69,7 +69,7 @@ hittable_rect_new hittable_box_new hittable_moving_sphere_new bvh_node_init hitt
 hittable_rotate_init hittable_constant_medium_init hittable_constant_medium_init_c hittable_flip_face_init
 hittable_free camera_new camera_free camera_fields camera_get_ray write_color ray_color material_free texture_free rt_scene_build rt_scene_set_image_path rt_write_png rt_write_ppm_p3""".split()
 RTC_SYMBOLS = """rtc_init rtc_last_error rtc_device_name rtc_device_count rtc_scene_build rtc_scene_flatten_only rtc_scene_save rtc_scene_load rtc_scene_load_host rtc_scene_free rtc_scene_num_prims
-rtc_scene_dump_leaves rtc_scene_bvh_info rtc_scene_small_info rtc_scene_dump_bvh rtc_scene_dump_bvh4 rtc_first_hit_f64 rtc_first_hit_f32 rtc_primary_first_hit_f64 rtc_render_device rtc_render_device_noalloc rtc_render rtc_render_stats
+rtc_scene_dump_leaves rtc_scene_bvh_info rtc_scene_small_info rtc_scene_extend_info rtc_scene_dump_bvh rtc_scene_dump_bvh4 rtc_first_hit_f64 rtc_first_hit_f32 rtc_primary_first_hit_f64 rtc_render_device rtc_render_device_noalloc rtc_render rtc_render_stats
 rtc_tonemap_u8_device rtc_tonemap_u8 rtc_ray_colors rtc_kat rtc_scene_clone_to_device rtc_render_multi make_scene free_scene render_scene render_scene_accumulate""".split()
 
 
@@ -142,6 +142,7 @@ def lib():
     L.rtc_scene_dump_leaves.argtypes = [_P, _dp, C.c_int]
     L.rtc_scene_bvh_info.argtypes = [_P, C.POINTER(C.c_longlong)]
     L.rtc_scene_small_info.argtypes = [_P, C.POINTER(C.c_int)]
+    L.rtc_scene_extend_info.argtypes = [_P, C.POINTER(C.c_int)]
     L.rtc_scene_dump_bvh.argtypes = [_P, _P, C.c_int, _P, _P, C.c_int]
     if hasattr(L, "rtc_scene_dump_bvh4"):   # (an older build named by RTC_LIB for an A/B run may lack the newest inspection call)
         L.rtc_scene_dump_bvh4.argtypes = [_P, _P, C.c_int, C.POINTER(C.c_int)]
@@ -260,6 +261,11 @@ class Scene:
         out = (C.c_int * 8)()
         _check(lib().rtc_scene_small_info(self.handle, out), "rtc_scene_small_info")
         return dict(zip(("eligible", "pairs", "spaces", "boxes", "spheres", "fused", "fused_rects", "fused_spheres"), out))
+
+    def extend_info(self):
+        out = (C.c_int * 4)()
+        _check(lib().rtc_scene_extend_info(self.handle, out), "rtc_scene_extend_info")
+        return dict(zip(("lds_tables", "lds_bytes", "nodes", "leaf_records"), out))
 
     def dump_bvh(self):
         """(nodes uint32[n, 16], leaves uint32[m, 16], prim_of_slot int32[m]); view the float fields with .view(np.float32)."""

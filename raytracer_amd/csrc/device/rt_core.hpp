@@ -214,6 +214,13 @@ struct LdsStack {
     RT_DEV void push(int x) { if (sp < cap) { base[sp * stride] = x; ++sp; } }
     RT_DEV int pop() { if (sp == 0) return RTC_BVH_EMPTY; --sp; return base[sp * stride]; }
 };
+// The same with 16-bit entries, for trees whose node indices and leaf references fit (k_wf_extend_lds: half the LDS per lane).
+struct LdsStack16 {
+    short *base; int stride, cap; int sp = 0;
+    RT_DEV LdsStack16(short *b, int s, int c) : base(b), stride(s), cap(c) {}
+    RT_DEV void push(int x) { if (sp < cap) { base[sp * stride] = (short)x; ++sp; } }
+    RT_DEV int pop() { if (sp == 0) return RTC_BVH_EMPTY; --sp; return (int)base[sp * stride]; }
+};
 struct HitS { float t; int prim, slot; };
 // One BLeaf against the ray: candidate parameter in [tmin, tmax] as sphere_t / rect_t accept it.  Written without early
 // returns: the leaf type is the only branch (usually wave-uniform), everything below it is selects, so the traversal
@@ -374,27 +381,34 @@ RT_DEV void bvh_leaf_step(const SceneT<float> &sc, const BLeaf &lf, BvhTrav &s, 
 // `if (node) { load; test } else { load; test }` the compiler waits for each arm's own load inside the arm (and moves
 // shared loads into the arms if they are not pinned), so a wave with lanes in both phases pays two dependent round
 // trips per trip.
+// node_tab / leaf_tab: the node and leaf tables as float4[4] records -- sc.nodes / sc.bleaves themselves, or a workgroup's copy of them
+// in LDS (k_wf_extend_lds / k_wf_extend_pool; the compiler sees the address space after inlining).
+#if !RT_BVH4
 template <int KINDS = RTC_KIND_ALL, typename Stack, typename MediumFn>
-RT_DEV HitS bvh_closest_hit(const SceneT<float> &sc, const RayT<float> &r, float tmin, float tmax, Stack &stack, MediumFn &&medium, int src_slot = -1) {
+RT_DEV void bvh_trip_tab(const SceneT<float> &sc, const float4 *node_tab, const float4 *leaf_tab, BvhTrav &s, float tmin, Stack &stack, MediumFn &&medium) {
+    const bool node = s.cur >= 0;
+    const float4 *ptr = node ? node_tab + 4 * s.cur : leaf_tab + 4 * ((~s.cur) >> 3);
+    float4 q0 = ptr[0], q1 = ptr[1], q2 = ptr[2], q3 = ptr[3];
+    asm volatile("" : "+v"(q0.x), "+v"(q1.x), "+v"(q2.x), "+v"(q3.x));   // pins the four loads here, ahead of both arms
+    if (node) {
+        BvhNode nd;
+        nd.lo0[0] = q0.x; nd.lo0[1] = q0.y; nd.lo0[2] = q0.z; nd.child0 = __float_as_int(q0.w); nd.hi0[0] = q1.x; nd.hi0[1] = q1.y; nd.hi0[2] = q1.z;
+        nd.lo1[0] = q2.x; nd.lo1[1] = q2.y; nd.lo1[2] = q2.z; nd.child1 = __float_as_int(q2.w); nd.hi1[0] = q3.x; nd.hi1[1] = q3.y; nd.hi1[2] = q3.z;
+        bvh_node_step(nd, s, tmin, stack);
+    } else {
+        BLeaf lf;
+        lf.d[0] = q0.x; lf.d[1] = q0.y; lf.d[2] = q0.z; lf.d[3] = q0.w; lf.d[4] = q1.x; lf.d[5] = q1.y; lf.d[6] = q1.z; lf.d[7] = q1.w;
+        lf.d[8] = q2.x; lf.d[9] = q2.y; lf.d[10] = q2.z; lf.d[11] = q2.w; lf.d[12] = q3.x; lf.d[13] = q3.y; lf.d[14] = q3.z; lf.meta = __float_as_uint(q3.w);
+        bvh_leaf_step<KINDS>(sc, lf, s, tmin, stack, medium);
+    }
+}
+#endif
+template <int KINDS = RTC_KIND_ALL, typename Stack, typename MediumFn>
+RT_DEV HitS bvh_closest_hit_tab(const SceneT<float> &sc, const float4 *node_tab, const float4 *leaf_tab, const RayT<float> &r, float tmin, float tmax,
+                                Stack &stack, MediumFn &&medium, int src_slot = -1) {
     BvhTrav s; bvh_begin(s, r, tmax, src_slot, sc.bvh_root);
 #if !RT_BVH4
-    while (s.cur != RTC_BVH_EMPTY) {
-        const bool node = s.cur >= 0;
-        const float4 *ptr = node ? reinterpret_cast<const float4 *>(sc.nodes + s.cur) : reinterpret_cast<const float4 *>(sc.bleaves + ((~s.cur) >> 3));
-        float4 q0 = ptr[0], q1 = ptr[1], q2 = ptr[2], q3 = ptr[3];
-        asm volatile("" : "+v"(q0.x), "+v"(q1.x), "+v"(q2.x), "+v"(q3.x));   // pins the four loads here, ahead of both arms
-        if (node) {
-            BvhNode nd;
-            nd.lo0[0] = q0.x; nd.lo0[1] = q0.y; nd.lo0[2] = q0.z; nd.child0 = __float_as_int(q0.w); nd.hi0[0] = q1.x; nd.hi0[1] = q1.y; nd.hi0[2] = q1.z;
-            nd.lo1[0] = q2.x; nd.lo1[1] = q2.y; nd.lo1[2] = q2.z; nd.child1 = __float_as_int(q2.w); nd.hi1[0] = q3.x; nd.hi1[1] = q3.y; nd.hi1[2] = q3.z;
-            bvh_node_step(nd, s, tmin, stack);
-        } else {
-            BLeaf lf;
-            lf.d[0] = q0.x; lf.d[1] = q0.y; lf.d[2] = q0.z; lf.d[3] = q0.w; lf.d[4] = q1.x; lf.d[5] = q1.y; lf.d[6] = q1.z; lf.d[7] = q1.w;
-            lf.d[8] = q2.x; lf.d[9] = q2.y; lf.d[10] = q2.z; lf.d[11] = q2.w; lf.d[12] = q3.x; lf.d[13] = q3.y; lf.d[14] = q3.z; lf.meta = __float_as_uint(q3.w);
-            bvh_leaf_step<KINDS>(sc, lf, s, tmin, stack, medium);
-        }
-    }
+    while (s.cur != RTC_BVH_EMPTY) bvh_trip_tab<KINDS>(sc, node_tab, leaf_tab, s, tmin, stack, medium);
 #else
     while (s.cur != RTC_BVH_EMPTY) {
         const bool node = s.cur >= 0;
@@ -417,6 +431,10 @@ RT_DEV HitS bvh_closest_hit(const SceneT<float> &sc, const RayT<float> &r, float
     s.h.prim = (int)s.n_steps;                                   // probe builds return the step count in place of the primitive id
 #endif
     return s.h;
+}
+template <int KINDS = RTC_KIND_ALL, typename Stack, typename MediumFn>
+RT_DEV HitS bvh_closest_hit(const SceneT<float> &sc, const RayT<float> &r, float tmin, float tmax, Stack &stack, MediumFn &&medium, int src_slot = -1) {
+    return bvh_closest_hit_tab<KINDS>(sc, reinterpret_cast<const float4 *>(sc.nodes), reinterpret_cast<const float4 *>(sc.bleaves), r, tmin, tmax, stack, medium, src_slot);
 }
 
 // Full hit record of the winning leaf: sphere_hit (:440-445) / rect_hit (:509-515), then the wrappers inside-out:

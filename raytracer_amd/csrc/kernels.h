@@ -58,6 +58,7 @@ size_t wf_bytes_per_slot();
 size_t wf_stats_bytes();
 hipError_t launch_wf_init(const CameraT<float> &cam, const RenderParams &p, const WfBuffers &b, hipStream_t stream);
 // one bounce: extend + shade over the first n_list entries of slot list `cur`
+bool wf_lds_tables(const SceneT<float> &sc, size_t *lds_bytes);   // extend from LDS-resident node / leaf tables (small trees)?
 hipError_t launch_wf_bounce(const SceneT<float> &sc, const CameraT<float> &cam, const RenderParams &p, const WfBuffers &b,
                             int cur, unsigned n_list, hipStream_t stream);
 // list `cur` -> list `cur ^ 1` without holes

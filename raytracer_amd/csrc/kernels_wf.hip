@@ -18,6 +18,8 @@
 // per-bounce path appends to a shared queue: slots die in place, and the compaction uses one atomic per 1024 entries.
 // Philox keys are the megakernel's: (pixel, sample, bounce) -- both kernels render the same estimator.
 #include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstdlib>
 
 #include "device/rt_shade.hpp"
 #include "kernels.h"
@@ -160,6 +162,62 @@ __global__ void __launch_bounds__(kWfExtendBlock) __attribute__((amdgpu_waves_pe
     }
 }
 
+// Extend for SMALL trees (book1: 281 nodes + 486 leaf records = 49 KB): a workgroup of 1024 threads copies the node and the leaf table
+// into LDS, and every trip's 64-byte fetch is four ds_read_b128 instead of a trip through the address unit, L1 and L2 -- which is
+// what the plain kernel waits for on such a scene (its lanes are coherent enough to outrun the L1's 64-byte-record rate).
+// Two workgroups per CU (8 waves per SIMD) need tables + stacks <= 80 KB each: the stacks hold 16-bit entries (wf_lds_tables()
+// checks that every node index and leaf reference fits).  Hits are bit-identical to k_wf_extend's: same traversal, same order.
+constexpr int kWfLdsBlock = 1024;
+template <int KINDS>
+__global__ void __launch_bounds__(kWfLdsBlock) k_wf_extend_lds(SceneT<float> sc, RenderParams P, WfBuffers B, int cur, unsigned n_list) {
+    const int n_leaf_recs = sc.n_bleaves;
+    extern __shared__ float4 lds_tab[];                              // nodes | leaves | stacks
+    float4 *const node_tab = lds_tab, *const leaf_tab = lds_tab + 4 * sc.n_nodes;
+    short *const stacks = reinterpret_cast<short *>(leaf_tab + 4 * n_leaf_recs);
+    {
+        const float4 *gn = reinterpret_cast<const float4 *>(sc.nodes), *gl = reinterpret_cast<const float4 *>(sc.bleaves);
+        for (int k = threadIdx.x; k < 4 * sc.n_nodes; k += kWfLdsBlock) node_tab[k] = gn[k];
+        for (int k = threadIdx.x; k < 4 * n_leaf_recs; k += kWfLdsBlock) leaf_tab[k] = gl[k];
+    }
+    __shared__ unsigned wg_next;
+    if (threadIdx.x == 0) wg_next = 0u;
+    __syncthreads();
+    // persistent: a workgroup owns a contiguous slice of the list's 64-entry chunks and its 16 waves claim them one at a time from a counter
+    // in LDS (a same-address atomic in HBM costs ~11 ns and serialises: one per chunk was 12 % slower than the static partition it replaced)
+    // -- no barrier after the copy, so a workgroup's waves do not wait for its slowest one, and the table is copied once per workgroup
+    unsigned long long n_rays = 0, n_waves = 0;
+    const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const unsigned n_chunks = (n_list + 63u) / 64u, per_wg = (n_chunks + gridDim.x - 1) / gridDim.x;
+    const unsigned wg_first = blockIdx.x * per_wg, wg_end = wg_first + per_wg < n_chunks ? wg_first + per_wg : n_chunks;
+    for (;;) {
+        unsigned chunk = 0;
+        if (lane == 0) chunk = atomicAdd(&wg_next, 1u);
+        chunk = wg_first + (unsigned)__builtin_amdgcn_readfirstlane((int)chunk);
+        if (chunk >= wg_end) break;
+        const unsigned i = chunk * 64u + lane;
+        const int slot = i < n_list ? B.active[cur][i] : -1;
+        const bool live = slot >= 0;
+        if (live) {
+            const float4 o = B.ro[slot], d = B.rd[slot];
+            const float4 tm = B.tm[slot];                            // throughput y z, sample | depth << 24, src slot
+            const int src_slot = __float_as_int(tm.w);
+            RayT<float> r; r.o = f3mk(o.x, o.y, o.z); r.d = f3mk(d.x, d.y, d.z); r.time = o.w;
+            NoMedium32 medium;
+            LdsStack16 stack(stacks + threadIdx.x, kWfLdsBlock, sc.bvh_stack);
+            const HitS h = bvh_closest_hit_tab<KINDS>(sc, node_tab, leaf_tab, r, 0.001f, Mth<float>::inf(), stack, medium, src_slot);   // ray.c:56
+            B.hit[slot] = make_float2(h.t, __int_as_float(h.slot));
+            const uint32_t lm = h.slot >= 0 ? __float_as_uint(leaf_tab[4 * h.slot + 3].w) : 0u;
+            B.key[slot] = h.slot >= 0 ? (unsigned char)(((lm >> 4) & 7u) * 4u + ((lm >> 8) & 3u)) : (unsigned char)31;
+        }
+        const unsigned long long mask = __builtin_amdgcn_ballot_w64(live);
+        n_rays += (unsigned long long)__builtin_popcountll(mask); n_waves += mask != 0;
+    }
+    if (lane == 0 && n_rays) {
+        atomicAdd(B.stats + 8 * (1 + ((blockIdx.x * 16 + wave) & (kWfStripes - 1))), n_rays);
+        atomicAdd(B.stats + 8 * (1 + kWfStripes + ((blockIdx.x * 16 + wave) & (kWfStripes - 1))), n_waves);
+    }
+}
+
 // Rays regrouped by material inside the workgroup: the kWfShadeBlock list entries of a block are counting-sorted in LDS by
 // (material type, texture type) of what they hit, then thread t shades the t-th entry of the sorted order.  Only slot
 // ids move (the path state stays where it is in HBM and the block's slots are neighbours, so the gathers stay inside a
@@ -299,6 +357,20 @@ __global__ void __launch_bounds__(256) k_wf_finish(RenderParams P, WfBuffers B, 
 size_t wf_bytes_per_slot() { return 4 * sizeof(float4) + sizeof(float2) + 2 * sizeof(int) + 1; }
 size_t wf_stats_bytes() { return (1 + 2 * kWfStripes) * 8 * sizeof(unsigned long long); }   // cache lines of 64 bytes
 
+// Does the extend stage of this scene run from LDS tables (k_wf_extend_lds)?  No media, every node index and leaf reference in 16
+// bits, and tables + 16-bit stacks of 1024 lanes within half a CU's LDS.  RTC_WF_LDS_TABLES=0 keeps the plain kernel (A/B, tests).
+bool wf_lds_tables(const SceneT<float> &sc, size_t *lds_bytes) {
+#if RT_BVH4
+    return false;   // the four-child A/B build traverses sc.nodes4 only
+#endif
+    if (const char *e = std::getenv("RTC_WF_LDS_TABLES")) if (std::atoi(e) == 0) return false;
+    if (sc.media_kind != 0 || sc.n_nodes <= 0 || sc.n_bleaves <= 0 || sc.n_nodes >= 32768 || sc.n_bleaves >= 4096) return false;   // ~(slot << 3 | count - 1) >= -32768
+    const size_t bytes = ((size_t)sc.n_nodes + (size_t)sc.n_bleaves) * 64 + (size_t)sc.bvh_stack * kWfLdsBlock * sizeof(short);
+    if (bytes + 64 > 80 * 1024) return false;
+    if (lds_bytes) *lds_bytes = bytes;
+    return true;
+}
+
 hipError_t launch_wf_init(const CameraT<float> &cam, const RenderParams &p, const WfBuffers &b, hipStream_t stream) {
     hipError_t e = hipMemsetAsync(b.counters, 0, 16 * sizeof(unsigned), stream);
     if (e == hipSuccess) e = hipMemsetAsync(b.stats + 8, 0, 2 * kWfStripes * 8 * sizeof(unsigned long long), stream);
@@ -311,7 +383,14 @@ hipError_t launch_wf_bounce(const SceneT<float> &sc, const CameraT<float> &cam, 
     if (n_list == 0) return hipSuccess;
     const unsigned blocks = (n_list + kWfExtendBlock - 1) / kWfExtendBlock;
     const size_t lds = (size_t)sc.bvh_stack * kWfExtendBlock * sizeof(int);
-    if (sc.media_kind == 0 && sc.leaf_kinds == RTC_KIND_SPHERE) hipLaunchKernelGGL((k_wf_extend<0, RTC_KIND_SPHERE>), dim3(blocks), dim3(kWfExtendBlock), lds, stream, sc, p, b, cur, n_list);
+    size_t lds_tab = 0;
+    if (wf_lds_tables(sc, &lds_tab)) {
+        static const unsigned n_cus = [] { int dev = 0, n = 256; if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return (unsigned)(n > 0 ? n : 256); }();
+        const unsigned lblocks = std::min((n_list + kWfLdsBlock - 1) / kWfLdsBlock, 2u * n_cus);   // persistent: two workgroups per CU
+        if (sc.leaf_kinds == RTC_KIND_SPHERE) hipLaunchKernelGGL((k_wf_extend_lds<RTC_KIND_SPHERE>), dim3(lblocks), dim3(kWfLdsBlock), lds_tab, stream, sc, p, b, cur, n_list);
+        else hipLaunchKernelGGL((k_wf_extend_lds<RTC_KIND_ALL>), dim3(lblocks), dim3(kWfLdsBlock), lds_tab, stream, sc, p, b, cur, n_list);
+    }
+    else if (sc.media_kind == 0 && sc.leaf_kinds == RTC_KIND_SPHERE) hipLaunchKernelGGL((k_wf_extend<0, RTC_KIND_SPHERE>), dim3(blocks), dim3(kWfExtendBlock), lds, stream, sc, p, b, cur, n_list);
     else if (sc.media_kind == 0) hipLaunchKernelGGL((k_wf_extend<0, RTC_KIND_ALL>), dim3(blocks), dim3(kWfExtendBlock), lds, stream, sc, p, b, cur, n_list);
     else if (sc.media_kind == 1) hipLaunchKernelGGL((k_wf_extend<1, RTC_KIND_ALL>), dim3(blocks), dim3(kWfExtendBlock), lds, stream, sc, p, b, cur, n_list);
     else hipLaunchKernelGGL((k_wf_extend<2, RTC_KIND_ALL>), dim3(blocks), dim3(kWfExtendBlock), lds, stream, sc, p, b, cur, n_list);

@@ -101,6 +101,7 @@ template <typename R> hipError_t upload_tables(const FlatScene &fs, DeviceTables
     v.bvh_stack = fs.bvh_depth < 1 ? 1 : fs.bvh_depth;   // one entry per level; flatten / load refuse trees deeper than RTC_BVH_MAX_DEPTH: nothing is clamped here
 #endif
     v.n_media = fs.n_media;
+    v.n_bleaves = (int)fs.bleaves.size();
     v.leaf_kinds = fs.leaf_kinds;
     v.tex_kinds = 0; for (const auto &t : fs.textures) v.tex_kinds |= 1 << t.type;
     v.media_kind = fs.n_media ? (fs.nodes.empty() ? 2 : fs.media_kind) : 0;
@@ -297,6 +298,15 @@ int rtc_scene_small_info(const rtc_scene *scene, int *out8) {
     for (const SmallSphere &sp : fs.small_spheres) fused_spheres += sp.pdf_k != 0.0f;
     out8[0] = fs.small_ok; out8[1] = (int)fs.small_pairs.size(); out8[2] = (int)fs.small_groups.size(); out8[3] = (int)fs.small_boxes.size();
     out8[4] = (int)fs.small_spheres.size(); out8[5] = fs.small_fused; out8[6] = fused_rects; out8[7] = fused_spheres;
+    return RTC_OK;
+}
+
+int rtc_scene_extend_info(const rtc_scene *scene, int *out4) {
+    if (!scene || !out4) return fail(RTC_ERR_ARG, "rtc_scene_extend_info: null argument");
+    if (scene->device < 0) return fail(RTC_ERR_DEVICE, "rtc_scene_extend_info: the scene has no device tables");
+    size_t lds = 0;
+    const bool on = wf_lds_tables(scene->f32.view, &lds);
+    out4[0] = on ? 1 : 0; out4[1] = (int)lds; out4[2] = scene->f32.view.n_nodes; out4[3] = scene->f32.view.n_bleaves;
     return RTC_OK;
 }
 

@@ -1040,3 +1040,60 @@ def test_light_pdf_fused_into_the_intersection_equals_the_light_loop(gpu, monkey
         rel = np.abs(a - b).sum() / a.sum()
         print(f"fused vs loop, weight {(0.1, 0.5)[k]}: sum |d| / sum = {rel:.2e}, max |d| = {np.abs(a - b).max():.3e}")
         assert rel <= 2e-5
+
+
+def test_extend_from_lds_tables_equals_the_plain_extend(gpu, monkeypatch):
+    """Small trees without media (book1: 281 nodes + 486 leaf records) are traversed from a copy of the node and leaf tables in LDS, with
+    16-bit stack entries (k_wf_extend_lds, kernels_wf.hip); RTC_WF_LDS_TABLES=0 keeps the plain kernel.  Same traversal, same visiting
+    order: the accumulators are bit-identical and the ray counts equal -- on the spheres-only scene and on a scene with every leaf kind
+    (box records, rotated boxes as quads, loose rects, spheres, moving spheres).  Scenes with media or larger trees keep the plain kernel."""
+    L = gpu.lib()
+    v3 = gpu.api.v3
+    rng = np.random.default_rng(5)
+
+    def all_kinds():
+        world = L.hittable_list_new(256)
+        mat = lambda: (L.material_lambertian_new_from_color(v3(tuple(rng.uniform(0.2, 0.9, 3)))) if rng.random() < 0.6 else
+                       (L.material_metal_new(v3((0.8, 0.8, 0.8)), 0.1) if rng.random() < 0.5 else L.material_dielectric_new(1.5)))
+        L.hittable_rect_new(world, -500, 500, 0, 0, -500, 500, 0, 1, mat())
+        for k in range(12):
+            b = L.hittable_box_new(None, v3((0, 0, 0)), v3(tuple(rng.uniform(30, 110, 3))), mat())
+            off = v3((float(rng.uniform(-400, 300)), float(rng.uniform(0, 150)), float(rng.uniform(-400, 300))))
+            b = L.hittable_translate_init(None, b, off) if k % 2 else L.hittable_translate_init(None, L.hittable_rotate_init(None, b, float(rng.uniform(-60, 60)), 1), off)
+            L.hittable_list_add(world, b)
+        for _ in range(20):
+            rad = float(rng.uniform(20, 60)); c = (float(rng.uniform(-400, 400)), rad + float(rng.uniform(0, 200)), float(rng.uniform(-400, 400)))
+            if rng.random() < 0.3: L.hittable_moving_sphere_new(world, v3(c), v3((c[0] + 30, c[1] + 20, c[2])), 0.0, 1.0, rad, mat())
+            else: L.hittable_sphere_new(world, v3(c), rad, mat())
+        sc = gpu.Scene(world, None, (0.5, 0.6, 0.8), 0.0, 1.0)
+        cam = gpu.Camera((100.0, 400.0, -1100.0), (0, 80, 0), (0, 1, 0), 45.0, 1.0, 0.0, 10.0, 0.0, 1.0)
+        return sc, cam, 6, 1
+
+    def book1():
+        sc, cam, view = gpu.build_named_scene("book1", aspect=1.5)
+        return sc, cam, view.max_depth, view.integrator
+
+    for make in (book1, all_kinds):
+        out = []
+        sc, cam, depth, integrator = make()
+        try:
+            for off in (False, True):
+                if off: monkeypatch.setenv("RTC_WF_LDS_TABLES", "0")
+                else: monkeypatch.delenv("RTC_WF_LDS_TABLES", raising=False)
+                info = sc.extend_info()
+                assert info["lds_tables"] == (0 if off else 1), info
+                if not off:
+                    assert info["lds_bytes"] <= 80 * 1024 and info["nodes"] > 0 and info["leaf_records"] > 64
+                acc, st = sc.render(cam, gpu.Settings(240, 160, 48, depth, integrator, seed=9, kernel=3))
+                assert st["kernel_used"] == 3
+                out.append((acc.copy(), st["rays"]))
+        finally:
+            sc.close()
+            monkeypatch.delenv("RTC_WF_LDS_TABLES", raising=False)
+        assert out[0][1] == out[1][1] and out[0][1] > 240 * 160 * 48
+        assert np.array_equal(out[0][0], out[1][0]) and out[0][0][..., :3].sum() > 0
+    sc, cam, view = gpu.build_named_scene("final")                     # media in the tree: the plain kernel
+    try:
+        assert sc.extend_info()["lds_tables"] == 0
+    finally:
+        sc.close()

@@ -58,14 +58,15 @@ RT_DEV f3 refract(f3 uv, f3 n, float eta) {                                     
 // v_sin_f32 / v_cos_f32 take revolutions: sin(2*pi*x) for x in [0,1) is one instruction
 RT_DEV float sin2pi(float x) { return __builtin_amdgcn_sinf(x); }
 RT_DEV float cos2pi(float x) { return __builtin_amdgcn_cosf(x); }
-RT_DEV f3 uniform_ball(float a, float b, float c) {      // same law as vec3_random_in_unit_sphere (vec3.c:66-72)
-    const float z = 1.0f - 2.0f * a, s = __builtin_amdgcn_sqrtf(fmaxf(0.0f, 1.0f - z * z));
-    const float rad = cbrtf(c);
-    return f3mk(s * cos2pi(b), s * sin2pi(b), z) * rad;
-}
 RT_DEV f3 uniform_sphere(float a, float b) {             // same law as vec3_random_unit_vector_in_unit_sphere
     const float z = 1.0f - 2.0f * a, s = __builtin_amdgcn_sqrtf(fmaxf(0.0f, 1.0f - z * z));
     return f3mk(s * cos2pi(b), s * sin2pi(b), z);
+}
+// radius of a uniform point in the unit ball: c^(1/3) as exp2(log2(c) / 3) -- v_log, v_mul, v_exp (c = 0 -> 0) instead of libm's
+// cbrtf (~40 instructions); the 1-2 ulp of the hardware log / exp are far below what a sampled radius needs
+RT_DEV float ball_radius(float c) { return __builtin_amdgcn_exp2f(__builtin_amdgcn_logf(c) * (1.0f / 3.0f)); }
+RT_DEV f3 uniform_ball(float a, float b, float c) {      // same law as vec3_random_in_unit_sphere (vec3.c:66-72)
+    return uniform_sphere(a, b) * ball_radius(c);
 }
 
 // pdf_cosine_value (pdf.c:100-103) == material_lambertian_scattering_pdf (material.c:205-208) for UNIT n and direction
@@ -294,13 +295,19 @@ RT_DEV int shade_hit_mat(const SceneT<float> &sc, PathState &ps, const RecT<floa
     auto tex = [&]() { return resolved ? f3mk(m.albedo[0], m.albedo[1], m.albedo[2]) : texture_value<NOISE>(sc, m.tex, rec.u, rec.v, rec.p); };
     const f3 d = ps.ray.d;
     RayT<float> next; next.o = rec.p; next.time = ps.ray.time;
+    // lambertian (02 / 01), fuzzy metal and the isotropic phase function all start from ONE uniform point on the unit sphere: drawn
+    // here, ahead of the switch, so that a wave whose lanes stand on different materials runs the sqrt / sin / cos sequence once
+    const bool ball = (m.type == RTC_MAT_METAL && m.param > 0.0f) || m.type == RTC_MAT_ISOTROPIC;
+    f3 us = f3mk(0, 0, 0);
+    if (ball || (m.type == RTC_MAT_LAMBERTIAN && integrator != 0)) us = uniform_sphere(xi.x, xi.y);
+    if (ball) us = us * ball_radius(xi.z);
     if (m.type == RTC_MAT_LIGHT) {                                                     // material.c:229-235 (03: front face only, F15)
         if (integrator != 2 && (integrator == 1 || rec.front)) ps.L = ps.L + ps.T * tex();
         return RT_TERMINATE;                                                           // material_light_scatter returns 0
     }
     if (m.type == RTC_MAT_METAL) {                                                     // material.c:130-138 / 02 :132-141
         const f3 reflected = reflect(normalize(d), rec.n);
-        next.d = m.param > 0.0f ? reflected + uniform_ball(xi.x, xi.y, xi.z) * m.param : reflected;
+        next.d = m.param > 0.0f ? reflected + us * m.param : reflected;
         if (integrator != 0 && !(dot(next.d, rec.n) > 0.0f)) return RT_TERMINATE;      // 02/01: absorbed
         ps.T = ps.T * f3mk(m.albedo[0], m.albedo[1], m.albedo[2]);
         ps.ray = next; return RT_CONTINUE;
@@ -311,14 +318,14 @@ RT_DEV int shade_hit_mat(const SceneT<float> &sc, PathState &ps, const RecT<floa
     }
     if (m.type == RTC_MAT_ISOTROPIC) {                                                 // 02 material.c:173-177; 03's is UB (F14) -> absorb
         if (integrator == 0) return RT_TERMINATE;
-        next.d = uniform_ball(xi.x, xi.y, xi.z);
+        next.d = us;
         ps.T = ps.T * tex();
         ps.ray = next; return RT_CONTINUE;
     }
     // lambertian
     const f3 att = tex();
     if (integrator != 0) {                                                             // 02 material.c:120-128
-        f3 dir = rec.n + uniform_sphere(xi.x, xi.y);
+        f3 dir = rec.n + us;
         if (fabsf(dir.x) < 1e-8f && fabsf(dir.y) < 1e-8f && fabsf(dir.z) < 1e-8f) dir = rec.n;
         next.d = dir; ps.T = ps.T * att; ps.ray = next; return RT_CONTINUE;
     }
@@ -350,6 +357,21 @@ template <bool NOISE = true>
 RT_DEV int shade_hit(const SceneT<float> &sc, PathState &ps, const RecT<float> &rec, int integrator, float light_weight, const Rng4 &xi) {
     const MaterialT<float> m = sc.materials[rec.mat];
     return shade_hit_mat<NOISE>(sc, ps, rec, m, false, integrator, light_weight, xi);
+}
+
+// main.c:150-152 + camera.c:46-53 for sample s of a pixel: jitter from words 0, 1 of the camera block; a thin lens takes words 2, 3
+// for its disk sample and the shutter time a block of its own; a pinhole camera (every reference scene) leaves words 2, 3 unused, so
+// the shutter time is word 2 and a primary ray costs ONE Philox block.  Shared by the general megakernel and the wavefront kernels.
+RT_DEV RayT<float> primary_ray_f32(const CameraT<float> &cam, int width, int height, bool use_time, uint32_t seed_lo, uint32_t seed_hi,
+                                   uint32_t pixel, int px, int py, uint32_t s) {
+    const Rng4 c = rng_block(pixel, s, RT_TAG_CAMERA, seed_lo, seed_hi);
+    const float u = ((float)px + c.x) / (float)(width - 1), v = ((float)py + c.y) / (float)(height - 1);
+    float dx = 0.0f, dy = 0.0f, tm = cam.time0;
+    if (cam.lens_radius > 0.0f) {
+        const float rr = __builtin_amdgcn_sqrtf(c.z); dx = rr * cos2pi(c.w); dy = rr * sin2pi(c.w);
+        if (use_time) tm = cam.time0 + (cam.time1 - cam.time0) * rng_block(pixel, s, RT_TAG_TIME, seed_lo, seed_hi).x;
+    } else if (use_time) tm = cam.time0 + (cam.time1 - cam.time0) * c.z;
+    return camera_ray<float>(cam, u, v, dx, dy, tm);
 }
 
 RT_DEV f3 sky_color(f3 dir) {                                                          // 01 main.c:59-64

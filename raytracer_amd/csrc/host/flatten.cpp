@@ -528,11 +528,12 @@ void build_bleaves(FlatScene &fs) {
     }
 }
 
-// Shading record of every leaf slot (the wavefront shade stage reads it by the hit's slot): the hit point needs only the
-// ray, the normal a world-space constant (rect: row of the collapsed rotation, like the quad leaf) or centre and 1/r
-// (sphere), the face flags follow hit_record_set_facenormal and the wrappers' re-facing (F11, flip_face), the colour is
-// resolved when the texture is a solid one.  Anything else -- a texture that must be evaluated, a moving sphere, a medium
-// -- is marked RTC_SF_GENERAL and goes through prims / chains / materials / textures as before.
+// Shading record of every leaf slot (the wavefront extend stage reads it by the hit's slot and shades the hit in its own tail): the hit
+// point needs only the ray, the normal a world-space constant (rect: row of the collapsed rotation, like the quad leaf) or centre and
+// 1/r (sphere; a moving sphere's centre is A + B time), the face flags follow hit_record_set_facenormal and the wrappers' re-facing
+// (F11, flip_face), the colour is resolved when the texture is a solid one; a constant medium needs its colour only.  Anything else --
+// a texture that must be evaluated, a chain whose facing the flags cannot express -- is marked RTC_SF_GENERAL and goes through
+// prims / chains / materials / textures in k_wf_shade.
 void chain_facing(const FlatScene &fs, int chain, bool &normal_ok, bool &front_ok, bool &flip);   // below, with its explanation
 void build_leaf_shade(FlatScene &fs) {
     fs.leaf_shade.clear();
@@ -545,14 +546,16 @@ void build_leaf_shade(FlatScene &fs) {
         bool normal_ok, front_ok;
         chain_facing(fs, p.chain, normal_ok, front_ok, flip);
         S.meta = (uint32_t)m.type | (wrapped ? RTC_SF_FORCED_FRONT : 0u) | (flip ? RTC_SF_FLIP : 0u);
-        bool general = p.type != RTC_PRIM_RECT && p.type != RTC_PRIM_SPHERE;
+        const uint32_t tex_kind = m.tex >= 0 ? (uint32_t)fs.textures[m.tex].type : 0u;
+        S.meta |= (((uint32_t)m.type * 4u + tex_kind) & 31u) << 16;                                  // k_wf_shade's regrouping key
+        bool general = false;
         if (!normal_ok || ((m.type == RTC_MAT_DIELECTRIC || m.type == RTC_MAT_LIGHT) && !front_ok)) general = true;   // replay the chain (resolve_hit)
         if (m.type == RTC_MAT_METAL) { for (int k = 0; k < 3; k++) S.rgb[k] = (float)m.albedo[k]; S.param = (float)m.param; }
         else if (m.type == RTC_MAT_DIELECTRIC) {   // pad[0] = 1 / ir, pad[1] = Schlick's r0 = ((1 - ir) / (1 + ir))^2 (the same for ir and 1 / ir)
             S.rgb[0] = S.rgb[1] = S.rgb[2] = 1.0f; S.param = (float)m.param; S.pad[0] = (float)(1.0 / m.param);
             const double r = (1.0 - m.param) / (1.0 + m.param); S.pad[1] = (float)(r * r);
         }
-        else if (m.type == RTC_MAT_ISOTROPIC || m.tex < 0 || fs.textures[m.tex].type != RTC_TEX_SOLID) general = true;
+        else if (m.tex < 0 || fs.textures[m.tex].type != RTC_TEX_SOLID) general = true;
         else for (int k = 0; k < 3; k++) S.rgb[k] = (float)fs.textures[m.tex].v[k];
         if (p.type == RTC_PRIM_RECT) {
             const int e = p.axis == RTC_AXIS_YZ ? 0 : (p.axis == RTC_AXIS_XZ ? 1 : 2);          // outward normal = +axis unit, object space
@@ -562,6 +565,19 @@ void build_leaf_shade(FlatScene &fs) {
             for (int k = 0; k < 3; k++) S.g[k] = (float)cw[k];
             S.g[3] = (float)(1.0 / p.d[3]);
             S.meta |= RTC_SF_SPHERE;
+        } else if (p.type == RTC_PRIM_MSPHERE) {   // centre(time) = A + B * time in world space, like the traversal leaf (build_bleaves)
+            if (m.type == RTC_MAT_DIELECTRIC) general = true;   // pad[] holds the glass constants
+            else {
+                double c0[3], c1[3]; to_world_point(M, b, p.d, c0); to_world_point(M, b, p.d + 3, c1);
+                const double t0 = p.d[6], t1 = p.d[7];
+                for (int k = 0; k < 3; k++) { const double B = (c1[k] - c0[k]) / (t1 - t0); S.pad[k] = (float)B; S.g[k] = (float)(c0[k] - B * t0); }
+                S.g[3] = (float)(1.0 / p.d[8]);
+                S.meta |= RTC_SF_SPHERE | RTC_SF_MOVING;
+            }
+        } else {                                   // constant medium: constant_medium_hit's record (normal (1,0,0), front_face 1: hittable.c:578-582)
+            S.meta |= RTC_SF_MEDIUM; S.meta &= ~(uint32_t)(RTC_SF_FORCED_FRONT | RTC_SF_FLIP);
+            S.g[0] = 1.0f;
+            if (m.type != RTC_MAT_ISOTROPIC && m.type != RTC_MAT_LAMBERTIAN && m.type != RTC_MAT_METAL) general = true;   // glass / lamps read front_face against a real surface
         }
         if (general) S.meta |= RTC_SF_GENERAL;
         fs.leaf_shade.push_back(S);

@@ -22,7 +22,7 @@
 namespace {
 
 const char kMagic[8] = {'R', 'T', 'C', 'S', 'C', 'E', 'N', 'E'};
-const uint32_t kVersion = 1;
+const uint32_t kVersion = 3;   // 2: glass constants in SmallShade.pad, 1/area in SmallPair, 32-byte SmallSphere (round 2); 3: leaf_shade carries moving spheres, media and the regrouping key
 
 struct Header { char magic[8]; uint32_t version, n_sections; uint64_t payload_bytes; uint32_t payload_crc, pad[9]; };
 static_assert(sizeof(Header) == 64, "header layout");

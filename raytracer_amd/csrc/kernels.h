@@ -42,6 +42,14 @@ hipError_t launch_accum_add(float4 *dst, const float4 *src, size_t n, hipStream_
 // ---- wavefront path tracer for BVH scenes (kernels_wf.hip) ----------------------------------------------------------
 // Path-slot state in HBM, SoA.  Slot s of layer k = s / slots_per_layer renders samples s_begin + k, + layers, ... of ONE
 // pixel (8x8 tiles, 64 consecutive slots per tile).
+// floor(x / d) for 0 <= x < 2^30 as (x * mul) >> shift: mul = ceil(2^shift / d), shift = 30 + ceil(log2 d)  (d >= 1; exact because
+// mul * d - 2^shift < d <= 2^(shift - 30))
+struct WfDiv { uint32_t mul, shift; };
+inline WfDiv wf_make_div(uint32_t d) {
+    uint32_t s = 0; while ((1ull << s) < d) ++s;
+    WfDiv r; r.shift = 30 + s; r.mul = (uint32_t)((((unsigned long long)1 << r.shift) + d - 1) / d);
+    return r;
+}
 struct WfBuffers {
     float4 *ro, *rd, *tm, *sum;       // origin | time, direction | throughput.x, throughput.yz | sample + (depth << 24) | leaf slot
                                       // the ray starts on (int bits), radiance sum of the slot; the pixel follows from the slot
@@ -53,6 +61,7 @@ struct WfBuffers {
     unsigned long long *stats_out;    // [0] rays, [1] extend waves of the calling stream: k_wf_finish folds the stripes into them
     int n_slots, slots_per_layer, layers;
     int quad;                         // slot <-> (pixel, layer) mapping of kernels_wf.hip slot_pixel
+    WfDiv div_group, div_tiles_x;     // divisions of that mapping: by the slots of a layer group (4 layers when quad, else 1), by tiles_x
 };
 size_t wf_bytes_per_slot();
 size_t wf_stats_bytes();

@@ -31,7 +31,6 @@ __global__ void __launch_bounds__(256) k_pathtrace_mega(SceneT<float> sc, Camera
     const int px = (tile % P.tiles_x) * 8 + (lane & 7), py = (tile / P.tiles_x) * 8 + (lane >> 3);
     const bool valid = px < P.width && py < P.height;
     const uint32_t pixel = (uint32_t)(py * P.width + px);
-    const float inv_w = 1.0f / (float)(P.width - 1), inv_h = 1.0f / (float)(P.height - 1);
 
     f3 sum = f3mk(0, 0, 0);
     unsigned nrays = 0, iters = 0;
@@ -46,12 +45,7 @@ __global__ void __launch_bounds__(256) k_pathtrace_mega(SceneT<float> sc, Camera
         if (P.max_depth <= 0) break;                                       // ray.c:52: depth 0 -> every sample is black (wave-uniform)
         if (!alive && valid && s_next < P.s_end) {                         // main.c:150-152 + camera.c:46-53
             s_cur = (uint32_t)s_next++;
-            const Rng4 c = rng_block(pixel, s_cur, RT_TAG_CAMERA, P.seed_lo, P.seed_hi);
-            const float u = ((float)px + c.x) * inv_w, v = ((float)py + c.y) * inv_h;
-            float dx = 0.0f, dy = 0.0f, tm = cam.time0;
-            if (cam.lens_radius > 0.0f) { const float rr = __builtin_amdgcn_sqrtf(c.z); dx = rr * cos2pi(c.w); dy = rr * sin2pi(c.w); }
-            if (P.use_time) tm = cam.time0 + (cam.time1 - cam.time0) * rng_block(pixel, s_cur, RT_TAG_TIME, P.seed_lo, P.seed_hi).x;
-            ps.ray = camera_ray<float>(cam, u, v, dx, dy, tm);
+            ps.ray = primary_ray_f32(cam, P.width, P.height, P.use_time != 0, P.seed_lo, P.seed_hi, pixel, px, py, s_cur);
             ps.T = f3mk(1, 1, 1); ps.L = f3mk(0, 0, 0);
             depth = 0; alive = true; src = -1;
         }

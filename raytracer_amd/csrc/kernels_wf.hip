@@ -24,10 +24,6 @@
 #include "device/rt_shade.hpp"
 #include "kernels.h"
 
-#ifndef RT_WF_REGROUP
-#define RT_WF_REGROUP 1   // 0: shade in list order (kept for the A/B measurement in DESIGN.md)
-#endif
-
 namespace {
 
 
@@ -41,35 +37,124 @@ __device__ __forceinline__ void wave_count_sub(unsigned *__restrict__ counter, b
 // multiple of 4): a 4x4-pixel quadrant of the tile in 4 consecutive layers -- the rays of a wave then start closer
 // together, and traversal length inside a wave diverges less (regrouping the list by material, which mixes 8 tiles
 // into a wave, costs 25 %: spatial coherence is worth more than a uniform material).
+// x / d for x < 2^30 through the multiplier the host has prepared (WfDiv, kernels.h): one 32 x 32 -> 64 multiply and a shift
+// instead of the ~25 instructions of a general unsigned division
+__device__ __forceinline__ int wf_div(int x, WfDiv d) { return (int)(((unsigned long long)(unsigned)x * d.mul) >> d.shift); }
 __device__ __forceinline__ void slot_pixel(const RenderParams &P, const WfBuffers &B, int slot, int &px, int &py, int &layer) {
     const int ns = B.slots_per_layer;
     int tile, x, y;
     if (B.quad) {
-        const int g = slot / (4 * ns), r = slot - g * 4 * ns;
+        const int g = wf_div(slot, B.div_group), r = slot - g * 4 * ns;
         tile = r >> 8;
         const int qd = (r >> 6) & 3, pq = r & 15;
         layer = 4 * g + ((r >> 4) & 3);
         x = (qd & 1) * 4 + (pq & 3); y = (qd >> 1) * 4 + (pq >> 2);
     } else {
-        layer = slot / ns;
+        layer = wf_div(slot, B.div_group);
         const int q = slot - layer * ns, lane = q & 63;
         tile = q >> 6; x = lane & 7; y = lane >> 3;
     }
-    px = (tile % P.tiles_x) * 8 + x; py = (tile / P.tiles_x) * 8 + y;
+    const int ty = wf_div(tile, B.div_tiles_x);
+    px = (tile - ty * P.tiles_x) * 8 + x; py = ty * 8 + y;
 }
 __device__ __forceinline__ int pixel_slot(const WfBuffers &B, int tile, int x, int y, int layer) {
     if (B.quad) return (layer >> 2) * 4 * B.slots_per_layer + tile * 256 + ((y >> 2) * 2 + (x >> 2)) * 64 + (layer & 3) * 16 + (y & 3) * 4 + (x & 3);
     return layer * B.slots_per_layer + tile * 64 + y * 8 + x;
 }
 
-// main.c:150-152 + camera.c:46-53 for sample s of a pixel (same Philox blocks as the megakernels)
 __device__ __forceinline__ RayT<float> primary_ray(const CameraT<float> &cam, const RenderParams &P, uint32_t pixel, int px, int py, uint32_t s) {
-    const Rng4 c = rng_block(pixel, s, RT_TAG_CAMERA, P.seed_lo, P.seed_hi);
-    const float u = ((float)px + c.x) / (float)(P.width - 1), v = ((float)py + c.y) / (float)(P.height - 1);
-    float dx = 0.0f, dy = 0.0f, tm = cam.time0;
-    if (cam.lens_radius > 0.0f) { const float rr = __builtin_amdgcn_sqrtf(c.z); dx = rr * cos2pi(c.w); dy = rr * sin2pi(c.w); }
-    if (P.use_time) tm = cam.time0 + (cam.time1 - cam.time0) * rng_block(pixel, s, RT_TAG_TIME, P.seed_lo, P.seed_hi).x;
-    return camera_ray<float>(cam, u, v, dx, dy, tm);
+    return primary_ray_f32(cam, P.width, P.height, P.use_time != 0, P.seed_lo, P.seed_hi, pixel, px, py, s);   // same Philox blocks as the megakernel
+}
+
+// ray.c:58-83 for ONE list entry whose closest hit is known, then the slot's bookkeeping: a finished path adds its radiance to the
+// slot's sum and the slot starts its next sample (or dies); otherwise the scattered ray is written back.  Returns true when the slot died.
+//   GENERAL = false: the hit's 48-byte shading record answers everything (leaf_shade: normal or centre, resolved colour, face flags) --
+//                    the form extend runs in its own tail, for every hit that is not marked RTC_SF_GENERAL;
+//   GENERAL = true : the leaf needs prims / chains / materials / textures (a texture to evaluate, a wrapper chain to replay): k_wf_shade.
+template <bool NOISE, bool GENERAL>
+__device__ __forceinline__ bool wf_shade_entry(const SceneT<float> &sc, const CameraT<float> &cam, const RenderParams &P, const WfBuffers &B, int slot,
+                                               int px, int py, const float4 &o, const float4 &d, const float4 &tm, float hit_t, int hslot, const SmallShade &sh) {
+    // sample, depth, leaf slot the ray starts on, pixel
+    int4 m = make_int4((int)(__float_as_uint(tm.z) & 0xffffffu), (int)(__float_as_uint(tm.z) >> 24), __float_as_int(tm.w), py * P.width + px);
+    PathState ps;
+    ps.ray.o = f3mk(o.x, o.y, o.z); ps.ray.d = f3mk(d.x, d.y, d.z); ps.ray.time = o.w;
+    ps.T = f3mk(d.w, tm.x, tm.y); ps.L = f3mk(0, 0, 0);
+    const uint32_t pixel = (uint32_t)m.w;
+    int status;
+    if (hslot < 0) {                                                 // ray.c:56: background (01: sky gradient)
+        const f3 bg = P.integrator == 2 ? sky_color(ps.ray.d) : f3mk(sc.background[0], sc.background[1], sc.background[2]);
+        ps.L = ps.T * bg;
+        status = RT_TERMINATE;
+    } else {
+        const Rng4 xi = rng_block(pixel, (uint32_t)m.x, (uint32_t)m.y, P.seed_lo, P.seed_hi);
+        if (!GENERAL) {
+            RecT<float> rec; rec.u = 0; rec.v = 0; rec.mat = 0;
+            rec.p = ps.ray.o + ps.ray.d * hit_t;                      // ray_at, ray.c:8-11
+            f3 gv = f3mk(sh.g[0], sh.g[1], sh.g[2]);
+            if (sh.meta & RTC_SF_MOVING) gv = gv + f3mk(sh.pad[0], sh.pad[1], sh.pad[2]) * ps.ray.time;   // moving_sphere_center, hittable.c:455-458
+            const f3 n_out = (sh.meta & RTC_SF_SPHERE) ? (rec.p - gv) * sh.g[3] : gv;
+            bool front = dot(ps.ray.d, n_out) < 0.0f;                 // hit_record_set_facenormal, hittable.c:13-16
+            rec.n = front ? n_out : -n_out;
+            if (sh.meta & RTC_SF_FORCED_FRONT) front = true;          // translate/rotate re-face an already faced normal (F11)
+            if (sh.meta & RTC_SF_FLIP) front = !front;                // flip_face_hit, hittable.c:587-591
+            if (sh.meta & RTC_SF_MEDIUM) { rec.n = f3mk(1, 0, 0); front = true; }   // constant_medium_hit, hittable.c:578-582
+            rec.front = front;
+            MaterialT<float> mat; mat.type = (int)(sh.meta & 0xffu); mat.tex = -1; mat.albedo[0] = sh.rgb[0]; mat.albedo[1] = sh.rgb[1]; mat.albedo[2] = sh.rgb[2]; mat.param = sh.param;
+            status = shade_hit_mat<false>(sc, ps, rec, mat, true, P.integrator, P.light_weight, xi);
+            m.z = (sh.meta & RTC_SF_MEDIUM) ? -1 : hslot;
+        } else {
+            const PrimT<float> p = sc.prims[sc.leaf_prims[hslot]];
+            const MaterialT<float> &mat = sc.materials[p.mat];
+            const RecT<float> rec = resolve_hit<float>(sc, ps.ray, p, hit_t, material_needs_uv(sc, mat));
+            status = shade_hit<NOISE>(sc, ps, rec, P.integrator, P.light_weight, xi);
+            m.z = p.type == RTC_PRIM_MEDIUM ? -1 : hslot;
+        }
+    }
+    ++m.y;
+    bool died = false;
+    if (status == RT_TERMINATE || m.y >= P.max_depth) {              // ray.c:52: depth exhausted adds nothing
+        const bool finite = (fabsf(ps.L.x) < 3.0e38f) && (fabsf(ps.L.y) < 3.0e38f) && (fabsf(ps.L.z) < 3.0e38f);
+        if (finite && (ps.L.x != 0.0f || ps.L.y != 0.0f || ps.L.z != 0.0f)) {
+            float4 s4 = B.sum[slot]; s4.x += ps.L.x; s4.y += ps.L.y; s4.z += ps.L.z; B.sum[slot] = s4;
+        }
+        m.x += B.layers;                                             // this slot's next sample
+        if (m.x < P.s_end) {
+            ps.ray = primary_ray(cam, P, pixel, px, py, (uint32_t)m.x);
+            ps.T = f3mk(1, 1, 1); m.y = 0; m.z = -1;
+        } else died = true;
+    }
+    if (!died) {
+        B.ro[slot] = make_float4(ps.ray.o.x, ps.ray.o.y, ps.ray.o.z, ps.ray.time);
+        B.rd[slot] = make_float4(ps.ray.d.x, ps.ray.d.y, ps.ray.d.z, ps.T.x);
+        B.tm[slot] = make_float4(ps.T.y, ps.T.z, __uint_as_float((uint32_t)m.x | ((uint32_t)m.y << 24)), __int_as_float(m.z));
+    }
+    return died;
+}
+// The extend kernels take their arguments as ONE struct, so that the tail can read them a second time: the bounce loop needs a
+// dozen scalars of them, the tail (camera, render parameters, buffer pointers) fifty more, and with everything live across the loop
+// the kernels spilled up to 86 SGPRs to vector lanes.  wf_args_again() hands out the kernel-argument segment through a pointer the
+// compiler cannot see through, so what is read through it is (re)loaded by s_load where the tail stands -- behind the loop.
+struct WfArgs { SceneT<float> sc; CameraT<float> cam; RenderParams P; WfBuffers B; int cur; unsigned n_list; };
+__device__ __forceinline__ const WfArgs &wf_args_again() {
+    const WfArgs __attribute__((address_space(4))) *p = (const WfArgs __attribute__((address_space(4))) *)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));
+    return *(const WfArgs *)p;
+}
+// The tail of both extend kernels: a hit whose shading record is complete is shaded where it was found -- the ray state is still in
+// registers, and 97-100 % of the hits of the reference's scenes are of that kind -- so the path state makes ONE trip through HBM per
+// bounce instead of two and k_wf_shade is left with the leaves that need a texture evaluated or a wrapper chain replayed (a scene
+// without such leaves does not launch it at all).  Measured: final 126 -> ... ms, 1M spheres 54 -> ... ms.
+__device__ __forceinline__ bool wf_extend_tail(const SceneT<float> &sc, const CameraT<float> &cam, const RenderParams &P, const WfBuffers &B, int slot,
+                                               int px, int py, const float4 &o, const float4 &d, const float4 &tm, const HitS &h) {
+    SmallShade sh; sh.meta = 0;
+    if (h.slot >= 0) sh = sc.leaf_shade[h.slot];
+    if (sh.meta & RTC_SF_GENERAL) {                                  // k_wf_shade's: park the hit and its regrouping key
+        B.hit[slot] = make_float2(h.t, __int_as_float(h.slot));
+        B.key[slot] = (unsigned char)((sh.meta >> 16) & 31u);
+        return false;
+    }
+    if (sc.n_general) B.key[slot] = (unsigned char)RTC_WF_KEY_DONE;
+    return wf_shade_entry<false, false>(sc, cam, P, B, slot, px, py, o, d, tm, h.t, h.slot, sh);
 }
 
 __global__ void __launch_bounds__(256) k_wf_init(CameraT<float> cam, RenderParams P, WfBuffers B) {
@@ -114,48 +199,36 @@ constexpr int kWfStripes = 64;   // cache lines each statistic is striped over
 #endif
 constexpr int kWfExtendBlock = RT_WF_EXTEND_BLOCK;
 template <int MEDIA, int KINDS>
-__global__ void __launch_bounds__(kWfExtendBlock) __attribute__((amdgpu_waves_per_eu(MEDIA == 2 ? 6 : 8))) k_wf_extend(SceneT<float> sc, RenderParams P, WfBuffers B, int cur, unsigned n_list) {
+__global__ void __launch_bounds__(kWfExtendBlock) __attribute__((amdgpu_waves_per_eu(MEDIA == 2 ? 6 : 8))) k_wf_extend(WfArgs a) {
+    const SceneT<float> &sc = a.sc; const RenderParams &P = a.P; const WfBuffers &B = a.B; const int cur = a.cur; const unsigned n_list = a.n_list;
     extern __shared__ int lds_stack[];                               // sc.bvh_stack entries per lane
     const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
     const int slot = i < n_list ? B.active[cur][i] : -1;
     const bool live = slot >= 0;
-#if RT_EXP == 3 || RT_EXP == 4
-    unsigned probe_n = 0;
-#endif
+    bool died = false;
     if (live) {
         const float4 o = B.ro[slot], d = B.rd[slot];
         const float4 tm = B.tm[slot];                                // throughput y z, sample | depth << 24, src slot
         const int src_slot = __float_as_int(tm.w);
         RayT<float> r; r.o = f3mk(o.x, o.y, o.z); r.d = f3mk(d.x, d.y, d.z); r.time = o.w;
+        int px, py, layer; slot_pixel(P, B, slot, px, py, layer);
         typename WfMedium<MEDIA>::type medium;
         if constexpr (MEDIA != 0) {
-            int px, py, layer; slot_pixel(P, B, slot, px, py, layer);
             const uint32_t sd = __float_as_uint(tm.z);
             medium.sc = &sc; medium.ray = &r; medium.tmin = 0.001f; medium.pixel = (uint32_t)(py * P.width + px); medium.sample = sd & 0xffffffu; medium.bounce = sd >> 24;
             medium.k0 = P.seed_lo; medium.k1 = P.seed_hi; medium.draws = 0;
         }
         LdsStack stack(lds_stack + threadIdx.x, kWfExtendBlock, sc.bvh_stack);
         const HitS h = bvh_closest_hit<KINDS>(sc, r, 0.001f, Mth<float>::inf(), stack, medium, src_slot);   // ray.c:56
-        B.hit[slot] = make_float2(h.t, __int_as_float(h.slot));
-        const uint32_t lm = h.slot >= 0 ? sc.bleaves[h.slot].meta : 0u;
-        B.key[slot] = h.slot >= 0 ? (unsigned char)(((lm >> 4) & 7u) * 4u + ((lm >> 8) & 3u)) : (unsigned char)31;
-#if RT_EXP == 3 || RT_EXP == 4
-        probe_n = (unsigned)h.prim;
-#endif
+        const WfArgs &t = wf_args_again();
+        died = wf_extend_tail(t.sc, t.cam, t.P, t.B, slot, px, py, o, d, tm, h);
+        if (died) t.B.active[t.cur][i] = -1;                         // stays in the list as a hole until the next compaction
     }
+    wave_count_sub(B.counters + 0, died);
     // statistics: two fire-and-forget atomics per block, striped over kWfStripes cache lines each
     const unsigned long long mask = __builtin_amdgcn_ballot_w64(live);
     const int rays = __syncthreads_count(live);
-#if RT_EXP == 3 || RT_EXP == 4   // probe: total node / leaf steps instead of the wave count
-    __shared__ unsigned probe_steps;
-    if (threadIdx.x == 0) probe_steps = 0;
-    __syncthreads();
-    if (live) atomicAdd(&probe_steps, probe_n);
-    __syncthreads();
-    const int waves = (int)probe_steps;
-#else
     const int waves = __syncthreads_count(mask != 0 && (threadIdx.x & 63) == 0);
-#endif
     if (threadIdx.x == 0 && rays) {
         atomicAdd(B.stats + 8 * (1 + (blockIdx.x & (kWfStripes - 1))), (unsigned long long)rays);
         atomicAdd(B.stats + 8 * (1 + kWfStripes + (blockIdx.x & (kWfStripes - 1))), (unsigned long long)waves);
@@ -169,7 +242,8 @@ __global__ void __launch_bounds__(kWfExtendBlock) __attribute__((amdgpu_waves_pe
 // checks that every node index and leaf reference fits).  Hits are bit-identical to k_wf_extend's: same traversal, same order.
 constexpr int kWfLdsBlock = 1024;
 template <int KINDS>
-__global__ void __launch_bounds__(kWfLdsBlock) k_wf_extend_lds(SceneT<float> sc, RenderParams P, WfBuffers B, int cur, unsigned n_list) {
+__global__ void __launch_bounds__(kWfLdsBlock) __attribute__((amdgpu_waves_per_eu(8))) k_wf_extend_lds(WfArgs a) {
+    const SceneT<float> &sc = a.sc; const RenderParams &P = a.P; const WfBuffers &B = a.B; const int cur = a.cur; const unsigned n_list = a.n_list;
     const int n_leaf_recs = sc.n_bleaves;
     extern __shared__ float4 lds_tab[];                              // nodes | leaves | stacks
     float4 *const node_tab = lds_tab, *const leaf_tab = lds_tab + 4 * sc.n_nodes;
@@ -197,6 +271,7 @@ __global__ void __launch_bounds__(kWfLdsBlock) k_wf_extend_lds(SceneT<float> sc,
         const unsigned i = chunk * 64u + lane;
         const int slot = i < n_list ? B.active[cur][i] : -1;
         const bool live = slot >= 0;
+        bool died = false;
         if (live) {
             const float4 o = B.ro[slot], d = B.rd[slot];
             const float4 tm = B.tm[slot];                            // throughput y z, sample | depth << 24, src slot
@@ -205,10 +280,12 @@ __global__ void __launch_bounds__(kWfLdsBlock) k_wf_extend_lds(SceneT<float> sc,
             NoMedium32 medium;
             LdsStack16 stack(stacks + threadIdx.x, kWfLdsBlock, sc.bvh_stack);
             const HitS h = bvh_closest_hit_tab<KINDS>(sc, node_tab, leaf_tab, r, 0.001f, Mth<float>::inf(), stack, medium, src_slot);   // ray.c:56
-            B.hit[slot] = make_float2(h.t, __int_as_float(h.slot));
-            const uint32_t lm = h.slot >= 0 ? __float_as_uint(leaf_tab[4 * h.slot + 3].w) : 0u;
-            B.key[slot] = h.slot >= 0 ? (unsigned char)(((lm >> 4) & 7u) * 4u + ((lm >> 8) & 3u)) : (unsigned char)31;
+            const WfArgs &t = wf_args_again();
+            int px, py, layer; slot_pixel(t.P, t.B, slot, px, py, layer);
+            died = wf_extend_tail(t.sc, t.cam, t.P, t.B, slot, px, py, o, d, tm, h);
+            if (died) t.B.active[t.cur][i] = -1;
         }
+        wave_count_sub(B.counters + 0, died);
         const unsigned long long mask = __builtin_amdgcn_ballot_w64(live);
         n_rays += (unsigned long long)__builtin_popcountll(mask); n_waves += mask != 0;
     }
@@ -218,10 +295,11 @@ __global__ void __launch_bounds__(kWfLdsBlock) k_wf_extend_lds(SceneT<float> sc,
     }
 }
 
-// Rays regrouped by material inside the workgroup: the kWfShadeBlock list entries of a block are counting-sorted in LDS by
-// (material type, texture type) of what they hit, then thread t shades the t-th entry of the sorted order.  Only slot
-// ids move (the path state stays where it is in HBM and the block's slots are neighbours, so the gathers stay inside a
-// few cache lines); a wave then runs one arm of the material switch instead of all of them.  No global atomics.
+// The hits extend has parked for this stage (leaves marked RTC_SF_GENERAL: a perlin / image / checker texture to evaluate, a wrapper
+// chain to replay), regrouped by material inside the workgroup: the parked entries of a block are counting-sorted in LDS by
+// (material type, texture type) of what they hit, then thread t shades the t-th entry of the sorted order.  Only slot ids move (the
+// path state stays where it is in HBM and the block's slots are neighbours, so the gathers stay inside a few cache lines); a wave
+// then runs one arm of the material switch instead of all of them.  No global atomics.  A block without parked entries returns.
 #ifndef RT_WF_SHADE_BLOCK
 #define RT_WF_SHADE_BLOCK 1024
 #endif
@@ -236,81 +314,31 @@ __global__ void __launch_bounds__(kWfShadeBlock) __attribute__((amdgpu_waves_per
     __shared__ unsigned sorted_index[kWfShadeBlock];
     unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
     int slot = i < n_list ? B.active[cur][i] : -1;
-#if RT_WF_REGROUP
     {
         if (threadIdx.x < 32) key_count[threadIdx.x] = 0;
         __syncthreads();
-        const unsigned key = slot >= 0 ? B.key[slot] & 31u : 0u;
+        unsigned key = slot >= 0 ? B.key[slot] : (unsigned)RTC_WF_KEY_DONE;
+        if (key == (unsigned)RTC_WF_KEY_DONE) slot = -1;             // shaded in extend's tail (or a hole)
+        key &= 31u;
         const unsigned rank = slot >= 0 ? atomicAdd(&key_count[key], 1u) : 0u;
         __syncthreads();
         if (threadIdx.x == 0) { unsigned acc = 0; for (int k = 0; k < 32; ++k) { key_start[k] = acc; acc += key_count[k]; } key_count[0] = acc; }
         __syncthreads();
         const unsigned total = key_count[0];
+        if (total == 0) return;                                      // block-uniform
         if (slot >= 0) { const unsigned pos = key_start[key] + rank; sorted_slot[pos] = slot; sorted_index[pos] = i; }
         __syncthreads();
         slot = threadIdx.x < total ? sorted_slot[threadIdx.x] : -1;
         i = threadIdx.x < total ? sorted_index[threadIdx.x] : 0u;
     }
-#endif
     bool died = false;
     if (slot >= 0) {
         const float4 o = B.ro[slot], d = B.rd[slot], tm = B.tm[slot];
         int px, py, layer; slot_pixel(P, B, slot, px, py, layer);
-        // sample, depth, leaf slot the ray starts on, pixel
-        int4 m = make_int4((int)(__float_as_uint(tm.z) & 0xffffffu), (int)(__float_as_uint(tm.z) >> 24), __float_as_int(tm.w), py * P.width + px);
         const float2 hh = B.hit[slot];
-        const int hslot = __float_as_int(hh.y);
-        PathState ps;
-        ps.ray.o = f3mk(o.x, o.y, o.z); ps.ray.d = f3mk(d.x, d.y, d.z); ps.ray.time = o.w;
-        ps.T = f3mk(d.w, tm.x, tm.y); ps.L = f3mk(0, 0, 0);
-        const uint32_t pixel = (uint32_t)m.w;
-        int status;
-        if (hslot < 0) {                                             // ray.c:56: background (01: sky gradient)
-            const f3 bg = P.integrator == 2 ? sky_color(ps.ray.d) : f3mk(sc.background[0], sc.background[1], sc.background[2]);
-            ps.L = ps.T * bg;
-            status = RT_TERMINATE;
-        } else {
-            const SmallShade sh = sc.leaf_shade[hslot];              // one read instead of leaf_prims -> prims -> chain -> materials -> textures
-            const Rng4 xi = rng_block(pixel, (uint32_t)m.x, (uint32_t)m.y, P.seed_lo, P.seed_hi);
-            if (!(sh.meta & RTC_SF_GENERAL)) {
-                RecT<float> rec; rec.u = 0; rec.v = 0; rec.mat = 0;
-                rec.p = ps.ray.o + ps.ray.d * hh.x;                   // ray_at, ray.c:8-11
-                const f3 gv = f3mk(sh.g[0], sh.g[1], sh.g[2]);
-                const f3 n_out = (sh.meta & RTC_SF_SPHERE) ? (rec.p - gv) * sh.g[3] : gv;
-                bool front = dot(ps.ray.d, n_out) < 0.0f;             // hit_record_set_facenormal, hittable.c:13-16
-                rec.n = front ? n_out : -n_out;
-                if (sh.meta & RTC_SF_FORCED_FRONT) front = true;      // translate/rotate re-face an already faced normal (F11)
-                if (sh.meta & RTC_SF_FLIP) front = !front;            // flip_face_hit, hittable.c:587-591
-                rec.front = front;
-                MaterialT<float> mat; mat.type = (int)(sh.meta & 0xffu); mat.tex = -1; mat.albedo[0] = sh.rgb[0]; mat.albedo[1] = sh.rgb[1]; mat.albedo[2] = sh.rgb[2]; mat.param = sh.param;
-                status = shade_hit_mat<NOISE>(sc, ps, rec, mat, true, P.integrator, P.light_weight, xi);
-                m.z = hslot;
-            } else {
-                const PrimT<float> p = sc.prims[sc.leaf_prims[hslot]];
-                const MaterialT<float> &mat = sc.materials[p.mat];
-                const RecT<float> rec = resolve_hit<float>(sc, ps.ray, p, hh.x, material_needs_uv(sc, mat));
-                status = shade_hit<NOISE>(sc, ps, rec, P.integrator, P.light_weight, xi);
-                m.z = p.type == RTC_PRIM_MEDIUM ? -1 : hslot;
-            }
-        }
-        ++m.y;
-        if (status == RT_TERMINATE || m.y >= P.max_depth) {          // ray.c:52: depth exhausted adds nothing
-            const bool finite = (fabsf(ps.L.x) < 3.0e38f) && (fabsf(ps.L.y) < 3.0e38f) && (fabsf(ps.L.z) < 3.0e38f);
-            if (finite && (ps.L.x != 0.0f || ps.L.y != 0.0f || ps.L.z != 0.0f)) {
-                float4 s4 = B.sum[slot]; s4.x += ps.L.x; s4.y += ps.L.y; s4.z += ps.L.z; B.sum[slot] = s4;
-            }
-            m.x += B.layers;                                         // this slot's next sample
-            if (m.x < P.s_end) {
-                ps.ray = primary_ray(cam, P, pixel, px, py, (uint32_t)m.x);
-                ps.T = f3mk(1, 1, 1); m.y = 0; m.z = -1;
-            } else died = true;
-        }
+        SmallShade none; none.meta = 0;
+        died = wf_shade_entry<NOISE, true>(sc, cam, P, B, slot, px, py, o, d, tm, hh.x, __float_as_int(hh.y), none);
         if (died) B.active[cur][i] = -1;                            // stays in the list as a hole until the next compaction
-        else {
-            B.ro[slot] = make_float4(ps.ray.o.x, ps.ray.o.y, ps.ray.o.z, ps.ray.time);
-            B.rd[slot] = make_float4(ps.ray.d.x, ps.ray.d.y, ps.ray.d.z, ps.T.x);
-            B.tm[slot] = make_float4(ps.T.y, ps.T.z, __uint_as_float((uint32_t)m.x | ((uint32_t)m.y << 24)), __int_as_float(m.z));
-        }
     }
     wave_count_sub(B.counters + 0, died);
 }
@@ -360,9 +388,6 @@ size_t wf_stats_bytes() { return (1 + 2 * kWfStripes) * 8 * sizeof(unsigned long
 // Does the extend stage of this scene run from LDS tables (k_wf_extend_lds)?  No media, every node index and leaf reference in 16
 // bits, and tables + 16-bit stacks of 1024 lanes within half a CU's LDS.  RTC_WF_LDS_TABLES=0 keeps the plain kernel (A/B, tests).
 bool wf_lds_tables(const SceneT<float> &sc, size_t *lds_bytes) {
-#if RT_BVH4
-    return false;   // the four-child A/B build traverses sc.nodes4 only
-#endif
     if (const char *e = std::getenv("RTC_WF_LDS_TABLES")) if (std::atoi(e) == 0) return false;
     if (sc.media_kind != 0 || sc.n_nodes <= 0 || sc.n_bleaves <= 0 || sc.n_nodes >= 32768 || sc.n_bleaves >= 4096) return false;   // ~(slot << 3 | count - 1) >= -32768
     const size_t bytes = ((size_t)sc.n_nodes + (size_t)sc.n_bleaves) * 64 + (size_t)sc.bvh_stack * kWfLdsBlock * sizeof(short);
@@ -384,16 +409,18 @@ hipError_t launch_wf_bounce(const SceneT<float> &sc, const CameraT<float> &cam, 
     const unsigned blocks = (n_list + kWfExtendBlock - 1) / kWfExtendBlock;
     const size_t lds = (size_t)sc.bvh_stack * kWfExtendBlock * sizeof(int);
     size_t lds_tab = 0;
+    const WfArgs args{sc, cam, p, b, cur, n_list};
     if (wf_lds_tables(sc, &lds_tab)) {
         static const unsigned n_cus = [] { int dev = 0, n = 256; if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return (unsigned)(n > 0 ? n : 256); }();
         const unsigned lblocks = std::min((n_list + kWfLdsBlock - 1) / kWfLdsBlock, 2u * n_cus);   // persistent: two workgroups per CU
-        if (sc.leaf_kinds == RTC_KIND_SPHERE) hipLaunchKernelGGL((k_wf_extend_lds<RTC_KIND_SPHERE>), dim3(lblocks), dim3(kWfLdsBlock), lds_tab, stream, sc, p, b, cur, n_list);
-        else hipLaunchKernelGGL((k_wf_extend_lds<RTC_KIND_ALL>), dim3(lblocks), dim3(kWfLdsBlock), lds_tab, stream, sc, p, b, cur, n_list);
+        if (sc.leaf_kinds == RTC_KIND_SPHERE) hipLaunchKernelGGL((k_wf_extend_lds<RTC_KIND_SPHERE>), dim3(lblocks), dim3(kWfLdsBlock), lds_tab, stream, args);
+        else hipLaunchKernelGGL((k_wf_extend_lds<RTC_KIND_ALL>), dim3(lblocks), dim3(kWfLdsBlock), lds_tab, stream, args);
     }
-    else if (sc.media_kind == 0 && sc.leaf_kinds == RTC_KIND_SPHERE) hipLaunchKernelGGL((k_wf_extend<0, RTC_KIND_SPHERE>), dim3(blocks), dim3(kWfExtendBlock), lds, stream, sc, p, b, cur, n_list);
-    else if (sc.media_kind == 0) hipLaunchKernelGGL((k_wf_extend<0, RTC_KIND_ALL>), dim3(blocks), dim3(kWfExtendBlock), lds, stream, sc, p, b, cur, n_list);
-    else if (sc.media_kind == 1) hipLaunchKernelGGL((k_wf_extend<1, RTC_KIND_ALL>), dim3(blocks), dim3(kWfExtendBlock), lds, stream, sc, p, b, cur, n_list);
-    else hipLaunchKernelGGL((k_wf_extend<2, RTC_KIND_ALL>), dim3(blocks), dim3(kWfExtendBlock), lds, stream, sc, p, b, cur, n_list);
+    else if (sc.media_kind == 0 && sc.leaf_kinds == RTC_KIND_SPHERE) hipLaunchKernelGGL((k_wf_extend<0, RTC_KIND_SPHERE>), dim3(blocks), dim3(kWfExtendBlock), lds, stream, args);
+    else if (sc.media_kind == 0) hipLaunchKernelGGL((k_wf_extend<0, RTC_KIND_ALL>), dim3(blocks), dim3(kWfExtendBlock), lds, stream, args);
+    else if (sc.media_kind == 1) hipLaunchKernelGGL((k_wf_extend<1, RTC_KIND_ALL>), dim3(blocks), dim3(kWfExtendBlock), lds, stream, args);
+    else hipLaunchKernelGGL((k_wf_extend<2, RTC_KIND_ALL>), dim3(blocks), dim3(kWfExtendBlock), lds, stream, args);
+    if (sc.n_general == 0) return hipGetLastError();               // every hit was shaded in extend's tail
     const dim3 sgrid((n_list + kWfShadeBlock - 1) / kWfShadeBlock);
     if (sc.tex_kinds & (1 << RTC_TEX_NOISE)) hipLaunchKernelGGL(k_wf_shade<true>, sgrid, dim3(kWfShadeBlock), 0, stream, sc, cam, p, b, cur, n_list);
     else hipLaunchKernelGGL(k_wf_shade<false>, sgrid, dim3(kWfShadeBlock), 0, stream, sc, cam, p, b, cur, n_list);

@@ -102,6 +102,7 @@ template <typename R> hipError_t upload_tables(const FlatScene &fs, DeviceTables
 #endif
     v.n_media = fs.n_media;
     v.n_bleaves = (int)fs.bleaves.size();
+    v.n_general = 0; for (const SmallShade &sh : fs.leaf_shade) v.n_general += (sh.meta & RTC_SF_GENERAL) != 0;
     v.leaf_kinds = fs.leaf_kinds;
     v.tex_kinds = 0; for (const auto &t : fs.textures) v.tex_kinds |= 1 << t.type;
     v.media_kind = fs.n_media ? (fs.nodes.empty() ? 2 : fs.media_kind) : 0;
@@ -477,7 +478,7 @@ static int render_wavefront(rtc_scene *s, const CameraT<float> &camf, const Rend
     b.counters = (unsigned *)((char *)s->ray_counter.p + wf_stats_bytes());
     b.n_slots = (int)n_slots; b.slots_per_layer = (int)per_layer; b.layers = (int)layers;
     b.quad = layers % 4 == 0;
-    if (const char *e = std::getenv("RTC_WF_QUAD")) b.quad = b.quad && std::atoi(e) != 0;   // A/B knob
+    b.div_group = wf_make_div((uint32_t)(b.quad ? 4 * per_layer : per_layer)); b.div_tiles_x = wf_make_div((uint32_t)p.tiles_x);
     HIP_TRY(launch_wf_init(camf, p, b, stream));
     const long long max_iterations = ((spp + layers - 1) / layers) * (long long)(p.max_depth > 0 ? p.max_depth : 1) + 1;
     unsigned n_list = (unsigned)n_slots;

@@ -95,6 +95,7 @@ template <typename R> struct SceneT {
     int tex_kinds;           // texture types in the scene: bit RTC_TEX_*
     int media_kind;          // BVH leaves: 0 no media, 1 sphere-bounded media only (BLeaf carries them), 2 general boundaries
     int n_bleaves;           // records of bleaves (one per leaf slot)
+    int n_general;           // leaf slots whose shading record is marked RTC_SF_GENERAL (0: the wavefront never launches k_wf_shade)
     R background[3];
 };
 // ---- small-scene pack (FP32 production path for scenes of <= 64 rect/sphere leaves with solid textures) --------------
@@ -116,7 +117,11 @@ template <typename R> struct SceneT {
 // bytes), then sphere s -> n_rects + s.
 enum { RTC_SMALL_MAX_LEAVES = 64, RTC_SMALL_MAX_XFORMS = 16 };
 enum { RTC_SF_FORCED_FRONT = 1u << 8, RTC_SF_FLIP = 1u << 9, RTC_SF_SPHERE = 1u << 10,   // SmallShade.meta bits; bits 0-7 = material type
-       RTC_SF_GENERAL = 1u << 11 };   // BVH leaf_shade only: not resolvable here (texture lookup, moving sphere, medium) -> prims / materials / textures
+       // BVH leaf_shade only:
+       RTC_SF_GENERAL = 1u << 11,     // not resolvable here (a texture to evaluate, a wrapper chain to replay) -> prims / materials / textures in k_wf_shade
+       RTC_SF_MOVING = 1u << 12,      // moving sphere: centre = g[0..2] + pad[0..2] * time (never glass: pad is the glass constants' place)
+       RTC_SF_MEDIUM = 1u << 13 };    // constant medium (isotropic phase function, no surface); bits 16-20: regrouping key of k_wf_shade = material type * 4 + texture type
+enum { RTC_WF_KEY_DONE = 255 };       // WfBuffers::key of an entry extend has shaded itself
 struct alignas(64) SmallPair { float f[16]; };
 struct alignas(32) SmallGroup { int xform, first, n_xy, n_xz, n_yz, box, rot_y, pad2; };   // box >= 0: SmallBox of this space, tested before the pairs;
                                                                                        // rot_y: the space's map leaves y alone up to a shift (m[1] = m[3] = m[5] = m[7] = 0, m[4] = 1)

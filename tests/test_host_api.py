@@ -161,23 +161,35 @@ def test_png_roundtrip(rtc, tmp_path):
 
 
 def test_png_against_the_reference_writer(rtc, tmp_path):
-    """The output edge of 03 main.c:170-171.  tests/golden/png_reference.npz holds a file written by the compiled reference's
-    stbi_flip_vertically_on_write(1) + stbi_write_png and the pixels it was given.  Both that file and rt_write_png's file of
-    the same pixels decode (PIL) to the same image, rows flipped.  The container BYTES differ -- stb compresses with its own
-    LZ matcher and picks a filter per row, rt_write_png uses filter 0 and zlib's deflate (stated in INTEGRATION.md) -- which no
-    PNG reader can tell apart."""
+    """The output edge of 03 main.c:170-171, byte for byte.  tests/golden/png_reference.npz holds files written by the compiled
+    reference's stbi_flip_vertically_on_write + stbi_write_png (stb_image_write v1.15, make_png_fixture.py) and the pixels they were
+    given: a structured image whose rows use all five filters, a noisy render, a one-pixel-wide image, a two-row image, a large flat
+    image (258-byte matches, the 32 KiB window) and one file written without the flip.  rt_write_png restates that writer -- the
+    per-row filter trial, its own fixed-Huffman deflate with the hash buckets of level 8 and lazy matching -- so the FILES are equal."""
     import io
     from PIL import Image
     fx = golden("png_reference.npz")
-    pixels, ref_png = fx["pixels"], fx["png"].tobytes()
-    ref_img = np.asarray(Image.open(io.BytesIO(ref_png)).convert("RGB"))
-    assert np.array_equal(ref_img, pixels[::-1])                       # the reference flips on write
-    p = str(tmp_path / "ours.png")
-    rtc.png_write(p, pixels, flip=True)
-    ours = open(p, "rb").read()
-    assert np.array_equal(np.asarray(Image.open(io.BytesIO(ours)).convert("RGB")), ref_img)
-    assert ours[:8] == ref_png[:8] and ours[8:33] == ref_png[8:33]     # signature and IHDR (size, 8-bit RGB, no interlace) are the same bytes
-    assert ours != ref_png                                             # ... the IDAT stream is not: documented, not hidden
+    names = sorted(k[len("pixels"):] for k in fx.files if k.startswith("pixels"))
+    assert len(names) >= 6
+    for sfx in names:
+        pixels, ref_png, flip = fx["pixels" + sfx], fx["png" + sfx].tobytes(), bool(fx["flip" + sfx])
+        ref_img = np.asarray(Image.open(io.BytesIO(ref_png)).convert("RGB"))
+        assert np.array_equal(ref_img, pixels[::-1] if flip else pixels)   # what the reference's file decodes to
+        p = str(tmp_path / "ours.png")
+        rtc.png_write(p, pixels, flip=flip)
+        ours = open(p, "rb").read()
+        assert ours == ref_png, f"case '{sfx}': {len(ours)} bytes against the reference's {len(ref_png)}"
+
+
+def test_png_rows_and_sizes_round_trip(rtc, tmp_path):
+    """Sizes around the encoder's edges (1 x 1, one row, one column, inputs shorter than the 3-byte hash) decode to the pixels given."""
+    from PIL import Image
+    rng = np.random.default_rng(3)
+    for h, w in ((1, 1), (1, 2), (2, 1), (1, 300), (300, 1), (5, 7)):
+        img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        p = str(tmp_path / "s.png")
+        rtc.png_write(p, img, flip=True)
+        assert np.array_equal(np.asarray(Image.open(p).convert("RGB")), img[::-1])
 
 
 def test_every_declared_symbol_is_exported(rtc):

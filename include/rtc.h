@@ -105,13 +105,6 @@ int  rtc_scene_extend_info(const rtc_scene *scene, int *out4);
  * Any pointer may be NULL; the caps are in entries.  Returns the number of leaf slots. */
 int  rtc_scene_dump_bvh(const rtc_scene *scene, void *nodes16, int node_cap, void *leaves16, int *prim_of_slot, int leaf_cap);
 
-/* The binary tree above collapsed to FOUR children per node on the host: the tree of the RT_BVH4 A/B build (the product
- * traverses the binary tree; the four-child traversal measured slower).  nodes32 = per node 32
- * words (float lo_x[4], lo_y[4], lo_z[4], hi_x[4], hi_y[4], hi_z[4], int child[4] encoded like the binary node's, 4 unused;
- * child 0x80000000 = no such child); *stack_entries = traversal stack entries per ray that tree needs.  Returns the number of
- * nodes (0 for a scene of at most 64 leaves, or when the tree needs more than 64 stack entries). */
-int  rtc_scene_dump_bvh4(const rtc_scene *scene, void *nodes32, int node_cap, int *stack_entries);
-
 /* FP64, no-FMA closest hit for n host rays (7 doubles each: orig, dir, time): bit-exact replacement of
  * hittable_list_hit(world, r, tmin, tmax, &rec) (hittable_list.c:125-143).  prim_id[i] = -1 on miss.
  * The kernel replays the reference's own traversal (list order; bvh_node_hit's left-then-right recursion over the tree

@@ -69,7 +69,7 @@ hittable_rect_new hittable_box_new hittable_moving_sphere_new bvh_node_init hitt
 hittable_rotate_init hittable_constant_medium_init hittable_constant_medium_init_c hittable_flip_face_init
 hittable_free camera_new camera_free camera_fields camera_get_ray write_color ray_color material_free texture_free rt_scene_build rt_scene_set_image_path rt_write_png rt_write_ppm_p3""".split()
 RTC_SYMBOLS = """rtc_init rtc_last_error rtc_device_name rtc_device_count rtc_scene_build rtc_scene_flatten_only rtc_scene_save rtc_scene_load rtc_scene_load_host rtc_scene_free rtc_scene_num_prims
-rtc_scene_dump_leaves rtc_scene_bvh_info rtc_scene_small_info rtc_scene_extend_info rtc_scene_dump_bvh rtc_scene_dump_bvh4 rtc_first_hit_f64 rtc_first_hit_f32 rtc_primary_first_hit_f64 rtc_render_device rtc_render_device_noalloc rtc_render rtc_render_stats
+rtc_scene_dump_leaves rtc_scene_bvh_info rtc_scene_small_info rtc_scene_extend_info rtc_scene_dump_bvh rtc_first_hit_f64 rtc_first_hit_f32 rtc_primary_first_hit_f64 rtc_render_device rtc_render_device_noalloc rtc_render rtc_render_stats
 rtc_tonemap_u8_device rtc_tonemap_u8 rtc_ray_colors rtc_kat rtc_scene_clone_to_device rtc_render_multi make_scene free_scene render_scene render_scene_accumulate""".split()
 
 
@@ -144,8 +144,6 @@ def lib():
     L.rtc_scene_small_info.argtypes = [_P, C.POINTER(C.c_int)]
     L.rtc_scene_extend_info.argtypes = [_P, C.POINTER(C.c_int)]
     L.rtc_scene_dump_bvh.argtypes = [_P, _P, C.c_int, _P, _P, C.c_int]
-    if hasattr(L, "rtc_scene_dump_bvh4"):   # (an older build named by RTC_LIB for an A/B run may lack the newest inspection call)
-        L.rtc_scene_dump_bvh4.argtypes = [_P, _P, C.c_int, C.POINTER(C.c_int)]
     L.rtc_first_hit_f64.argtypes = [_P, _dp, C.c_size_t, C.c_double, C.c_double, _P, _dp, _dp]
     L.rtc_first_hit_f32.argtypes = [_P, _dp, C.c_size_t, C.c_double, C.c_double, _P, _P]
     L.rtc_primary_first_hit_f64.argtypes = [_P, _P, _dp, _dp, C.c_size_t, C.c_double, C.c_double, _P, _dp, _dp]
@@ -277,14 +275,6 @@ class Scene:
         if n < 0:
             raise RtcError("rtc_scene_dump_bvh: " + lib().rtc_last_error().decode())
         return nodes[:info["nodes"]], leaves[:n], prims[:n]
-
-    def dump_bvh4(self):
-        """(nodes uint32[n, 32], stack entries): the four-child tree the GPU traverses; float fields via .view(np.float32)."""
-        st = C.c_int(0)
-        n = lib().rtc_scene_dump_bvh4(self.handle, None, 0, C.byref(st))
-        nodes = np.zeros((max(n, 1), 32), dtype=np.uint32)
-        lib().rtc_scene_dump_bvh4(self.handle, nodes.ctypes.data, n, C.byref(st))
-        return nodes[:n], st.value
 
     def first_hit(self, rays7, tmin=0.001, tmax=np.inf, want_rec=False):
         rays7 = np.ascontiguousarray(rays7, dtype=np.float64)

@@ -279,17 +279,10 @@ RT_DEV bool bleaf_t(const BLeaf &lf, const RayT<float> &r, float tmin, float tma
         return sphere_roots_f32(mk3<float>(lf.d[0] + lf.d[3] * r.time, lf.d[1] + lf.d[4] * r.time, lf.d[2] + lf.d[5] * r.time), lf.d[6], r, tmin, tmax, from_here, t);
     return false;
 }
-// One loop, one step per trip: a lane either tests the two child boxes of an inner node or one leaf primitive, so lanes
-// of a wave that are in different phases of their traversal never wait for each other's inner loops.  The nearer child
-// is entered first; the farther one waits on the stack.
-#ifndef RT_EXP
-#define RT_EXP 0   // development probes; 0 in every shipped build
-#endif
+// The traversal loop.  A lane stands on an inner node (cur >= 0) or on a leaf record (cur < 0); the nearer child is entered first,
+// the farther one waits on the stack.
 struct BvhTrav {
     RayT<float> r; V3<float> inv, noi; HitS h; int cur, src_slot;   // src_slot = leaf slot the ray starts on (-1: none)
-#if RT_EXP == 3 || RT_EXP == 4
-    unsigned n_steps = 0;                                        // probe: node (3) or leaf (4) steps of this ray
-#endif
 };
 RT_DEV void bvh_begin(BvhTrav &s, const RayT<float> &r, float tmax, int src_slot, int root) {
     // 1/d clamped to +-1e30: a zero component must not turn lo * inv - o * inv into inf - inf (slab_f32)
@@ -298,20 +291,8 @@ RT_DEV void bvh_begin(BvhTrav &s, const RayT<float> &r, float tmax, int src_slot
     s.noi = mk3<float>(-r.o.x * s.inv.x, -r.o.y * s.inv.y, -r.o.z * s.inv.z);
     s.h.t = tmax; s.h.prim = -1; s.h.slot = -1; s.cur = root; s.src_slot = src_slot;
 }
-// RT_BVH4 = 1: A/B build that traverses the four-child tree (rtc_tables.h BvhNode4) instead of the two-child one.  Measured
-// SLOWER on every BVH scene (final +21 %, 1M spheres +13 %, book1 +4 %, profiles/r02b): a step tests four boxes and orders
-// them for ~2.4x the VALU instructions of a two-child step while the steps per ray only fall to ~0.55x, and the deeper stack
-// (up to three entries per level) costs LDS occupancy.  These kernels are bound by VALU issue under divergence, not by the
-// length of the dependent fetch chain, so the product traverses the binary tree.
-#ifndef RT_BVH4
-#define RT_BVH4 0
-#endif
-#if !RT_BVH4
 template <typename Stack>
 RT_DEV void bvh_node_step(const BvhNode &nd, BvhTrav &s, float tmin, Stack &stack) {
-#if RT_EXP == 3
-    ++s.n_steps;
-#endif
     float n0, n1;
     const bool h0 = slab_f32(nd.lo0, nd.hi0, s.noi, s.inv, tmin, s.h.t, n0), h1 = slab_f32(nd.lo1, nd.hi1, s.noi, s.inv, tmin, s.h.t, n1);
     const bool both = h0 & h1, first0 = h0 & ((n0 <= n1) | !h1);   // the only hit child, or the nearer of two
@@ -319,43 +300,8 @@ RT_DEV void bvh_node_step(const BvhNode &nd, BvhTrav &s, float tmin, Stack &stac
     s.cur = first0 ? nd.child0 : nd.child1;
     if (!(h0 | h1)) s.cur = stack.pop();
 }
-#else
-// One inner node = four child boxes (BvhNode4, component-major: q[0..5] = lo x, y, z and hi x, y, z of the four children,
-// qc = their refs).  The hit children are ordered by entry distance with a five-comparator network on integer keys --
-// a positive float orders like its bit pattern, so key = (bits of tn with the two lowest bits replaced by the child's
-// position), +inf for a miss; min/max on the keys sort distance and identity together -- the nearest is entered, the others
-// wait on the stack, farthest first.
-template <typename Stack>
-RT_DEV void bvh_node4_step(const float4 &lox, const float4 &loy, const float4 &loz, const float4 &hix, const float4 &hiy, const float4 &hiz, const float4 &qc,
-                           BvhTrav &s, float tmin, Stack &stack) {
-#if RT_EXP == 3
-    ++s.n_steps;
-#endif
-    const int c0 = __float_as_int(qc.x), c1 = __float_as_int(qc.y), c2 = __float_as_int(qc.z), c3 = __float_as_int(qc.w);
-    auto key = [&](float lx, float ly, float lz, float hx, float hy, float hz, int child, uint32_t pos) -> uint32_t {
-        const float lo[3] = {lx, ly, lz}, hi[3] = {hx, hy, hz};
-        float tn;
-        const bool hit = slab_f32(lo, hi, s.noi, s.inv, tmin, s.h.t, tn) & (child != RTC_BVH_EMPTY);
-        return hit ? ((__float_as_uint(tn) & ~3u) | pos) : (0x7f800000u | pos);
-    };
-    uint32_t k0 = key(lox.x, loy.x, loz.x, hix.x, hiy.x, hiz.x, c0, 0u), k1 = key(lox.y, loy.y, loz.y, hix.y, hiy.y, hiz.y, c1, 1u);
-    uint32_t k2 = key(lox.z, loy.z, loz.z, hix.z, hiy.z, hiz.z, c2, 2u), k3 = key(lox.w, loy.w, loz.w, hix.w, hiy.w, hiz.w, c3, 3u);
-    auto cswap = [](uint32_t &a, uint32_t &b) { const uint32_t lo = a < b ? a : b, hi = a < b ? b : a; a = lo; b = hi; };
-    cswap(k0, k1); cswap(k2, k3); cswap(k0, k2); cswap(k1, k3); cswap(k1, k2);
-    auto child_at = [&](uint32_t k) { const uint32_t p = k & 3u; return p == 0u ? c0 : (p == 1u ? c1 : (p == 2u ? c2 : c3)); };
-    const uint32_t miss = 0x7f800000u;
-    if (k3 < miss) stack.push(child_at(k3));
-    if (k2 < miss) stack.push(child_at(k2));
-    if (k1 < miss) stack.push(child_at(k1));
-    s.cur = child_at(k0);
-    if (!(k0 < miss)) s.cur = stack.pop();
-}
-#endif
 template <int KINDS = RTC_KIND_ALL, typename Stack, typename MediumFn>
 RT_DEV void bvh_leaf_step(const SceneT<float> &sc, const BLeaf &lf, BvhTrav &s, float tmin, Stack &stack, MediumFn &&medium) {
-#if RT_EXP == 4
-    ++s.n_steps;
-#endif
     const int v = ~s.cur, slot = v >> 3, rem = v & 7;
     int hit_slot = slot, width = 1;                              // a box record answers for six slots
     float t; bool hit;
@@ -376,14 +322,19 @@ RT_DEV void bvh_leaf_step(const SceneT<float> &sc, const BLeaf &lf, BvhTrav &s, 
     if (hit) { s.h.t = t; s.h.slot = hit_slot; }
     s.cur = rem ? ~(((slot + width) << 3) | (rem - 1)) : stack.pop();
 }
+// One loop, one step per trip: a lane either tests the two child boxes of an inner node or one leaf record, so lanes of a wave that
+// are in different phases of their traversal never wait for each other's inner loops.
 // One trip = one memory round trip for the whole wave: every lane requests the 64 bytes it stands on at the top of the
 // trip (a node or a leaf, through one address), and only then do the two arms run.  Written as
 // `if (node) { load; test } else { load; test }` the compiler waits for each arm's own load inside the arm (and moves
 // shared loads into the arms if they are not pinned), so a wave with lanes in both phases pays two dependent round
 // trips per trip.
+// (Round 3, measured and dropped: TWO steps per trip -- a lane on the last record of a leaf run pops its stack at the top of the trip
+// and requests the node that comes off together with the leaf, so the node arm of the same trip takes it one step further; same
+// visiting order, bit-identical hits, fewer trips -- and 9-17 % SLOWER on every BVH scene: eight dwordx4 requests per trip through an
+// address unit that is already busy two thirds of the time, and 16 more registers.  tools/patches/bvh_two_steps_per_trip.patch.)
 // node_tab / leaf_tab: the node and leaf tables as float4[4] records -- sc.nodes / sc.bleaves themselves, or a workgroup's copy of them
-// in LDS (k_wf_extend_lds / k_wf_extend_pool; the compiler sees the address space after inlining).
-#if !RT_BVH4
+// in LDS (k_wf_extend_lds; the compiler sees the address space after inlining).
 template <int KINDS = RTC_KIND_ALL, typename Stack, typename MediumFn>
 RT_DEV void bvh_trip_tab(const SceneT<float> &sc, const float4 *node_tab, const float4 *leaf_tab, BvhTrav &s, float tmin, Stack &stack, MediumFn &&medium) {
     const bool node = s.cur >= 0;
@@ -402,34 +353,12 @@ RT_DEV void bvh_trip_tab(const SceneT<float> &sc, const float4 *node_tab, const 
         bvh_leaf_step<KINDS>(sc, lf, s, tmin, stack, medium);
     }
 }
-#endif
 template <int KINDS = RTC_KIND_ALL, typename Stack, typename MediumFn>
 RT_DEV HitS bvh_closest_hit_tab(const SceneT<float> &sc, const float4 *node_tab, const float4 *leaf_tab, const RayT<float> &r, float tmin, float tmax,
                                 Stack &stack, MediumFn &&medium, int src_slot = -1) {
     BvhTrav s; bvh_begin(s, r, tmax, src_slot, sc.bvh_root);
-#if !RT_BVH4
     while (s.cur != RTC_BVH_EMPTY) bvh_trip_tab<KINDS>(sc, node_tab, leaf_tab, s, tmin, stack, medium);
-#else
-    while (s.cur != RTC_BVH_EMPTY) {
-        const bool node = s.cur >= 0;
-        const float4 *ptr = node ? reinterpret_cast<const float4 *>(sc.nodes4 + s.cur) : reinterpret_cast<const float4 *>(sc.bleaves + ((~s.cur) >> 3));
-        float4 q0 = ptr[0], q1 = ptr[1], q2 = ptr[2], q3 = ptr[3];
-        float4 q4 = q0, q5 = q0, q6 = q0;                            // a node is 112 bytes, a leaf 64: three more loads for the lanes on a node
-        if (node) { q4 = ptr[4]; q5 = ptr[5]; q6 = ptr[6]; }
-        asm volatile("" : "+v"(q0.x), "+v"(q1.x), "+v"(q2.x), "+v"(q3.x), "+v"(q4.x), "+v"(q5.x), "+v"(q6.x));   // pins the loads here, ahead of both arms
-        if (node) bvh_node4_step(q0, q1, q2, q3, q4, q5, q6, s, tmin, stack);
-        else {
-            BLeaf lf;
-            lf.d[0] = q0.x; lf.d[1] = q0.y; lf.d[2] = q0.z; lf.d[3] = q0.w; lf.d[4] = q1.x; lf.d[5] = q1.y; lf.d[6] = q1.z; lf.d[7] = q1.w;
-            lf.d[8] = q2.x; lf.d[9] = q2.y; lf.d[10] = q2.z; lf.d[11] = q2.w; lf.d[12] = q3.x; lf.d[13] = q3.y; lf.d[14] = q3.z; lf.meta = __float_as_uint(q3.w);
-            bvh_leaf_step<KINDS>(sc, lf, s, tmin, stack, medium);
-        }
-    }
-#endif
     s.h.prim = s.h.slot >= 0 ? sc.leaf_prims[s.h.slot] : -1;
-#if RT_EXP == 3 || RT_EXP == 4
-    s.h.prim = (int)s.n_steps;                                   // probe builds return the step count in place of the primitive id
-#endif
     return s.h;
 }
 template <int KINDS = RTC_KIND_ALL, typename Stack, typename MediumFn>

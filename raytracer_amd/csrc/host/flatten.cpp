@@ -848,56 +848,6 @@ void mark_small_lights(FlatScene &fs) {
     fs.small_fused = true;
 }
 
-// Binary tree -> four-child tree.  A node4 starts with the two children of a binary node; while it has fewer than four, the
-// INNER child with the largest box surface is replaced by its own two children (the box most likely to be hit is opened
-// first: fewer, fuller steps).  Pre-order numbering (every child behind its parent, like the binary table).  The traversal
-// enters the nearest hit child and pushes the others, so a path from the root needs sum(children - 1) stack entries at most.
-bool build_bvh4(FlatScene &out) {
-    out.nodes4.clear(); out.bvh_stack = 0;
-    if (out.nodes.empty()) return true;
-    struct C { float lo[3], hi[3]; int ref; };
-    auto area = [](const C &c) { const double d[3] = {(double)c.hi[0] - c.lo[0], (double)c.hi[1] - c.lo[1], (double)c.hi[2] - c.lo[2]}; return d[0] * d[1] + d[1] * d[2] + d[2] * d[0]; };
-    auto children_of = [&](int b, C *dst) {
-        const BvhNode &nd = out.nodes[(size_t)b];
-        for (int a = 0; a < 3; a++) { dst[0].lo[a] = nd.lo0[a]; dst[0].hi[a] = nd.hi0[a]; dst[1].lo[a] = nd.lo1[a]; dst[1].hi[a] = nd.hi1[a]; }
-        dst[0].ref = nd.child0; dst[1].ref = nd.child1;
-    };
-    const int n_bin = (int)out.nodes.size();
-    bool ok = true;
-    // explicit stack instead of recursion: (binary node, slot of the parent node4 that waits for this node4's index)
-    struct Job { int bin, parent, slot, need_above; };
-    std::vector<Job> jobs; jobs.push_back({0, -1, 0, 0});
-    out.nodes4.reserve(out.nodes.size() / 2 + 1);
-    while (!jobs.empty()) {
-        const Job j = jobs.back(); jobs.pop_back();
-        C c[4]; int n = 2;
-        children_of(j.bin, c);
-        if (c[1].ref == RTC_BVH_EMPTY) n = 1;                      // the one-leaf scene's root
-        while (n < 4) {
-            int best = -1; double best_area = -1;
-            for (int k = 0; k < n; k++) if (c[k].ref >= 0 && c[k].ref < n_bin && area(c[k]) > best_area) { best = k; best_area = area(c[k]); }
-            if (best < 0) break;
-            C two[2]; children_of(c[best].ref, two);
-            c[best] = two[0]; c[n++] = two[1];
-        }
-        const int me = (int)out.nodes4.size();
-        BvhNode4 nd; std::memset(&nd, 0, sizeof nd);
-        for (int k = 0; k < 4; k++) {
-            if (k < n) { nd.lox[k] = c[k].lo[0]; nd.loy[k] = c[k].lo[1]; nd.loz[k] = c[k].lo[2]; nd.hix[k] = c[k].hi[0]; nd.hiy[k] = c[k].hi[1]; nd.hiz[k] = c[k].hi[2]; nd.child[k] = c[k].ref; }
-            else { nd.lox[k] = nd.loy[k] = nd.loz[k] = 1.0f; nd.hix[k] = nd.hiy[k] = nd.hiz[k] = -1.0f; nd.child[k] = RTC_BVH_EMPTY; }
-        }
-        out.nodes4.push_back(nd);
-        if (j.parent >= 0) out.nodes4[(size_t)j.parent].child[j.slot] = me;
-        const int need = j.need_above + (n - 1);
-        if (need > out.bvh_stack) out.bvh_stack = need;
-        // children in REVERSE order onto the job stack, so that child 0's subtree is numbered first (pre-order)
-        for (int k = n - 1; k >= 0; k--) if (c[k].ref >= 0) { if (c[k].ref >= n_bin) ok = false; else jobs.push_back({c[k].ref, me, k, need}); }
-    }
-    if (out.bvh_stack < 1) out.bvh_stack = 1;
-    if (!ok) { out.error = "BVH child index out of range"; return false; }
-    if (out.bvh_stack > RTC_BVH_MAX_STACK) { out.nodes4.clear(); out.bvh_stack = 0; }   // too deep for the four-child traversal (A/B builds refuse the scene); the product walks the binary tree
-    return true;
-}
 
 bool flatten_scene(const hittable_list *world, const hittable_list *lights, const color *background,
                    double time0, double time1, int bvh_threshold, FlatScene &out) {
@@ -961,8 +911,6 @@ bool flatten_scene(const hittable_list *world, const hittable_list *lights, cons
         // the traversal stack holds one entry per level: a deeper tree must be refused, not clamped (a dropped push is a missed hit).
         // The builder's own bound is 40 SAH levels + log2(n) median levels, i.e. this needs more than 2^24 leaves in one chain.
         if (max_depth > RTC_BVH_MAX_DEPTH) { out.error = "the BVH is " + std::to_string(max_depth) + " levels deep (limit " + std::to_string((int)RTC_BVH_MAX_DEPTH) + ")"; return false; }
-        if (!build_bvh4(out)) return false;
-        lap("bvh4");
         build_bleaves(out);
         lap("leaves");
         build_leaf_shade(out);

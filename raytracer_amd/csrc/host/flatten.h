@@ -22,8 +22,6 @@ struct FlatScene {
     std::vector<BLeaf> bleaves;     // FP32 traversal leaves, one per slot of leaf_prims
     std::vector<SmallShade> leaf_shade;   // shading record per slot of leaf_prims (rtc_tables.h SmallShade, RTC_SF_GENERAL)
     int bvh_depth = 0;              // levels of the binary BVH (root = 1)
-    std::vector<BvhNode4> nodes4;   // what the GPU traverses: the binary tree collapsed to four children per node (build_bvh4); derived, not stored in scene files
-    int bvh_stack = 0;              // traversal stack entries the four-child tree needs (<= RTC_BVH_MAX_STACK)
     std::vector<int> box_first;     // first primitive of every hittable box (its 6 sides follow in creation order)
     std::vector<int> box_slots;     // leaf slots where an axis-aligned box record starts (it owns 6 slots: BLeaf, rtc_tables.h)
     std::vector<RefStep> ref_steps; // the reference's own traversal, depth-first (FP64 check path)
@@ -49,9 +47,6 @@ struct FlatScene {
     std::string error;
 };
 
-// nodes -> nodes4 + bvh_stack (deterministic; also run after a scene file is loaded).  False + out.error when the tree needs
-// a deeper traversal stack than RTC_BVH_MAX_STACK.
-bool build_bvh4(FlatScene &out);
 // lights -> leaves of the small-scene pack (deterministic; also run after a scene file is loaded)
 void mark_small_lights(FlatScene &fs);
 

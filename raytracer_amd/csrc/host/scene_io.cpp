@@ -249,7 +249,6 @@ bool load_flat_scene(const char *path, FlatScene &fs, std::string &err) {
     for (int k = 0; k < 3; k++) fs.background[k] = sc.background[k];
     std::string why;
     if (!validate_flat_scene(fs, why)) { err = std::string(path) + ": " + why; return false; }
-    if (!build_bvh4(fs)) { err = std::string(path) + ": " + fs.error; return false; }
     mark_small_lights(fs);                                            // derived from the verified lights and pack, like the four-child tree   // the traversed four-child tree is derived from the verified binary one
     return true;
 }

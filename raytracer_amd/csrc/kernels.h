@@ -54,7 +54,7 @@ struct WfBuffers {
     float4 *ro, *rd, *tm, *sum;       // origin | time, direction | throughput.x, throughput.yz | sample + (depth << 24) | leaf slot
                                       // the ray starts on (int bits), radiance sum of the slot; the pixel follows from the slot
     float2 *hit;                      // t, leaf slot (int bits; -1 = miss) written by extend
-    unsigned char *key;               // regrouping key of the hit written by extend: material type * 4 + texture type, 31 = miss
+    unsigned char *key;               // per LIST position, written by extend: regrouping key of a hit parked for k_wf_shade (material type * 4 + texture type), RTC_WF_KEY_DONE otherwise
     int *active[2];                   // slot lists (ping-pong across compactions); -1 = hole
     unsigned *counters;               // 16 words: [0] live slots, [1] compaction cursor
     unsigned long long *stats;        // wf_stats_bytes(): 16 striped partial counters (rays, extend waves) behind one unused line; scene-wide like the pool

@@ -26,6 +26,9 @@
 
 namespace {
 
+#ifndef RT_WF_SUM_ATOMIC
+#define RT_WF_SUM_ATOMIC 0   // 1: no-return atomics instead of the read-modify-write; measured 1-3 % slower (round 3)
+#endif
 
 // live-slot counter: one atomic per wave that has something to report (a slot dies once per render)
 __device__ __forceinline__ void wave_count_sub(unsigned *__restrict__ counter, bool pred) {
@@ -115,7 +118,14 @@ __device__ __forceinline__ bool wf_shade_entry(const SceneT<float> &sc, const Ca
     if (status == RT_TERMINATE || m.y >= P.max_depth) {              // ray.c:52: depth exhausted adds nothing
         const bool finite = (fabsf(ps.L.x) < 3.0e38f) && (fabsf(ps.L.y) < 3.0e38f) && (fabsf(ps.L.z) < 3.0e38f);
         if (finite && (ps.L.x != 0.0f || ps.L.y != 0.0f || ps.L.z != 0.0f)) {
+            // fire-and-forget adds (global_atomic_add_f32 without return): the wave does not wait for a load as a read-modify-write
+            // would make it; a slot is touched by ONE lane per launch and launches are ordered, so the sum is the same from run to run
+#if RT_WF_SUM_ATOMIC
+            float *sum = reinterpret_cast<float *>(B.sum + slot);
+            unsafeAtomicAdd(sum + 0, ps.L.x); unsafeAtomicAdd(sum + 1, ps.L.y); unsafeAtomicAdd(sum + 2, ps.L.z);
+#else
             float4 s4 = B.sum[slot]; s4.x += ps.L.x; s4.y += ps.L.y; s4.z += ps.L.z; B.sum[slot] = s4;
+#endif
         }
         m.x += B.layers;                                             // this slot's next sample
         if (m.x < P.s_end) {
@@ -145,15 +155,14 @@ __device__ __forceinline__ const WfArgs &wf_args_again() {
 // bounce instead of two and k_wf_shade is left with the leaves that need a texture evaluated or a wrapper chain replayed (a scene
 // without such leaves does not launch it at all).  Measured: final 126 -> ... ms, 1M spheres 54 -> ... ms.
 __device__ __forceinline__ bool wf_extend_tail(const SceneT<float> &sc, const CameraT<float> &cam, const RenderParams &P, const WfBuffers &B, int slot,
-                                               int px, int py, const float4 &o, const float4 &d, const float4 &tm, const HitS &h) {
+                                               int px, int py, const float4 &o, const float4 &d, const float4 &tm, const HitS &h, unsigned char &key) {
     SmallShade sh; sh.meta = 0;
     if (h.slot >= 0) sh = sc.leaf_shade[h.slot];
     if (sh.meta & RTC_SF_GENERAL) {                                  // k_wf_shade's: park the hit and its regrouping key
         B.hit[slot] = make_float2(h.t, __int_as_float(h.slot));
-        B.key[slot] = (unsigned char)((sh.meta >> 16) & 31u);
+        key = (unsigned char)((sh.meta >> 16) & 31u);
         return false;
     }
-    if (sc.n_general) B.key[slot] = (unsigned char)RTC_WF_KEY_DONE;
     return wf_shade_entry<false, false>(sc, cam, P, B, slot, px, py, o, d, tm, h.t, h.slot, sh);
 }
 
@@ -198,14 +207,18 @@ constexpr int kWfStripes = 64;   // cache lines each statistic is striped over
 #define RT_WF_EXTEND_BLOCK 64
 #endif
 constexpr int kWfExtendBlock = RT_WF_EXTEND_BLOCK;
+#ifndef RT_WF_EXTEND_WAVES
+#define RT_WF_EXTEND_WAVES 8   // resident waves per SIMD the register budget of extend is set for (A/B knob)
+#endif
 template <int MEDIA, int KINDS>
-__global__ void __launch_bounds__(kWfExtendBlock) __attribute__((amdgpu_waves_per_eu(MEDIA == 2 ? 6 : 8))) k_wf_extend(WfArgs a) {
+__global__ void __launch_bounds__(kWfExtendBlock) __attribute__((amdgpu_waves_per_eu(MEDIA == 2 ? 6 : RT_WF_EXTEND_WAVES))) k_wf_extend(WfArgs a) {
     const SceneT<float> &sc = a.sc; const RenderParams &P = a.P; const WfBuffers &B = a.B; const int cur = a.cur; const unsigned n_list = a.n_list;
     extern __shared__ int lds_stack[];                               // sc.bvh_stack entries per lane
     const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
     const int slot = i < n_list ? B.active[cur][i] : -1;
     const bool live = slot >= 0;
     bool died = false;
+    unsigned char key = (unsigned char)RTC_WF_KEY_DONE;
     if (live) {
         const float4 o = B.ro[slot], d = B.rd[slot];
         const float4 tm = B.tm[slot];                                // throughput y z, sample | depth << 24, src slot
@@ -221,9 +234,10 @@ __global__ void __launch_bounds__(kWfExtendBlock) __attribute__((amdgpu_waves_pe
         LdsStack stack(lds_stack + threadIdx.x, kWfExtendBlock, sc.bvh_stack);
         const HitS h = bvh_closest_hit<KINDS>(sc, r, 0.001f, Mth<float>::inf(), stack, medium, src_slot);   // ray.c:56
         const WfArgs &t = wf_args_again();
-        died = wf_extend_tail(t.sc, t.cam, t.P, t.B, slot, px, py, o, d, tm, h);
+        died = wf_extend_tail(t.sc, t.cam, t.P, t.B, slot, px, py, o, d, tm, h, key);
         if (died) t.B.active[t.cur][i] = -1;                         // stays in the list as a hole until the next compaction
     }
+    if (sc.n_general && i < n_list) B.key[i] = key;                  // by LIST position: k_wf_shade scans them with coalesced reads
     wave_count_sub(B.counters + 0, died);
     // statistics: two fire-and-forget atomics per block, striped over kWfStripes cache lines each
     const unsigned long long mask = __builtin_amdgcn_ballot_w64(live);
@@ -272,6 +286,7 @@ __global__ void __launch_bounds__(kWfLdsBlock) __attribute__((amdgpu_waves_per_e
         const int slot = i < n_list ? B.active[cur][i] : -1;
         const bool live = slot >= 0;
         bool died = false;
+        unsigned char key = (unsigned char)RTC_WF_KEY_DONE;
         if (live) {
             const float4 o = B.ro[slot], d = B.rd[slot];
             const float4 tm = B.tm[slot];                            // throughput y z, sample | depth << 24, src slot
@@ -282,9 +297,10 @@ __global__ void __launch_bounds__(kWfLdsBlock) __attribute__((amdgpu_waves_per_e
             const HitS h = bvh_closest_hit_tab<KINDS>(sc, node_tab, leaf_tab, r, 0.001f, Mth<float>::inf(), stack, medium, src_slot);   // ray.c:56
             const WfArgs &t = wf_args_again();
             int px, py, layer; slot_pixel(t.P, t.B, slot, px, py, layer);
-            died = wf_extend_tail(t.sc, t.cam, t.P, t.B, slot, px, py, o, d, tm, h);
+            died = wf_extend_tail(t.sc, t.cam, t.P, t.B, slot, px, py, o, d, tm, h, key);
             if (died) t.B.active[t.cur][i] = -1;
         }
+        if (sc.n_general && i < n_list) B.key[i] = key;
         wave_count_sub(B.counters + 0, died);
         const unsigned long long mask = __builtin_amdgcn_ballot_w64(live);
         n_rays += (unsigned long long)__builtin_popcountll(mask); n_waves += mask != 0;
@@ -296,51 +312,76 @@ __global__ void __launch_bounds__(kWfLdsBlock) __attribute__((amdgpu_waves_per_e
 }
 
 // The hits extend has parked for this stage (leaves marked RTC_SF_GENERAL: a perlin / image / checker texture to evaluate, a wrapper
-// chain to replay), regrouped by material inside the workgroup: the parked entries of a block are counting-sorted in LDS by
-// (material type, texture type) of what they hit, then thread t shades the t-th entry of the sorted order.  Only slot ids move (the
-// path state stays where it is in HBM and the block's slots are neighbours, so the gathers stay inside a few cache lines); a wave
-// then runs one arm of the material switch instead of all of them.  No global atomics.  A block without parked entries returns.
-#ifndef RT_WF_SHADE_BLOCK
-#define RT_WF_SHADE_BLOCK 1024
-#endif
-constexpr int kWfShadeBlock = RT_WF_SHADE_BLOCK;
-#ifndef RT_WF_SHADE_WAVES
-#define RT_WF_SHADE_WAVES 5
-#endif
+// chain to replay).  They may be few -- the final scene's perlin sphere is 2-3 % of the hits -- and a wave that shades 6 of them
+// among 58 idle lanes issues the 200 table loads of the turbulence at full price: the address unit takes a load instruction as
+// long whatever the number of lanes (a launch of the one-block-per-1024-entries form: 530 us for 16.7 M entries).  So a persistent
+// workgroup walks its share of the list 1024 entries at a time, queues what is parked in LDS, and shades only when 1024 entries
+// wait (and once more at the end): dense waves whatever the density of the list.  The queued entries are counting-sorted in LDS
+// by (material type, texture type) of what they hit, so a wave runs one arm of the material switch instead of all of them.
+// Only slot ids move; no global atomics; the order of the work is a function of the list alone.
+constexpr int kWfShadeBlock = 1024;
 template <bool NOISE>
-__global__ void __launch_bounds__(kWfShadeBlock) __attribute__((amdgpu_waves_per_eu(NOISE ? RT_WF_SHADE_WAVES : 6))) k_wf_shade(SceneT<float> sc, CameraT<float> cam, RenderParams P, WfBuffers B, int cur, unsigned n_list) {
-    __shared__ unsigned key_count[32], key_start[32];
-    __shared__ int sorted_slot[kWfShadeBlock];
-    __shared__ unsigned sorted_index[kWfShadeBlock];
-    unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
-    int slot = i < n_list ? B.active[cur][i] : -1;
-    {
-        if (threadIdx.x < 32) key_count[threadIdx.x] = 0;
-        __syncthreads();
-        unsigned key = slot >= 0 ? B.key[slot] : (unsigned)RTC_WF_KEY_DONE;
-        if (key == (unsigned)RTC_WF_KEY_DONE) slot = -1;             // shaded in extend's tail (or a hole)
-        key &= 31u;
-        const unsigned rank = slot >= 0 ? atomicAdd(&key_count[key], 1u) : 0u;
-        __syncthreads();
-        if (threadIdx.x == 0) { unsigned acc = 0; for (int k = 0; k < 32; ++k) { key_start[k] = acc; acc += key_count[k]; } key_count[0] = acc; }
-        __syncthreads();
-        const unsigned total = key_count[0];
-        if (total == 0) return;                                      // block-uniform
-        if (slot >= 0) { const unsigned pos = key_start[key] + rank; sorted_slot[pos] = slot; sorted_index[pos] = i; }
-        __syncthreads();
-        slot = threadIdx.x < total ? sorted_slot[threadIdx.x] : -1;
-        i = threadIdx.x < total ? sorted_index[threadIdx.x] : 0u;
+__global__ void __launch_bounds__(kWfShadeBlock) __attribute__((amdgpu_waves_per_eu(NOISE ? 5 : 6))) k_wf_shade(SceneT<float> sc, CameraT<float> cam, RenderParams P, WfBuffers B, int cur, unsigned n_list) {
+    constexpr unsigned N = kWfShadeBlock;
+    __shared__ int q_slot[2 * N];
+    __shared__ unsigned q_index[2 * N];
+    __shared__ unsigned char q_key[2 * N];
+    __shared__ unsigned wave_count[N / 64], key_count[32], key_start[32];
+    __shared__ int sorted_slot[N];
+    __shared__ unsigned sorted_index[N];
+    const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const unsigned n_chunks = (n_list + N - 1) / N;
+    unsigned q_n = 0;                                                // block-uniform: every thread keeps the same count
+    for (unsigned c = blockIdx.x;; c += gridDim.x) {
+        const bool flush = c >= n_chunks;                            // one trip past the end: shade what is still queued
+        if (!flush) {
+            const unsigned i = c * N + tid;
+            const unsigned key = i < n_list ? B.key[i] : (unsigned)RTC_WF_KEY_DONE;   // DONE: shaded in extend's tail, or a hole of the list
+            const bool parked = key != (unsigned)RTC_WF_KEY_DONE;
+            const unsigned long long mask = __builtin_amdgcn_ballot_w64(parked);
+            if (lane == 0) wave_count[wave] = (unsigned)__builtin_popcountll(mask);
+            __syncthreads();
+            unsigned before = 0, total = 0;
+            for (unsigned w = 0; w < N / 64; ++w) { const unsigned n = wave_count[w]; before += w < wave ? n : 0u; total += n; }
+            if (parked) {
+                const unsigned pos = q_n + before + (unsigned)__builtin_popcountll(mask & ((1ull << lane) - 1ull));
+                q_slot[pos] = B.active[cur][i]; q_index[pos] = i; q_key[pos] = (unsigned char)(key & 31u);
+            }
+            __syncthreads();
+            q_n += total;
+        }
+        if (q_n >= N || (flush && q_n > 0)) {
+            const unsigned take = q_n < N ? q_n : N;
+            if (tid < 32) key_count[tid] = 0;
+            __syncthreads();
+            const unsigned key = tid < take ? q_key[tid] : 0u;
+            const unsigned rank = tid < take ? atomicAdd(&key_count[key], 1u) : 0u;
+            __syncthreads();
+            if (tid == 0) { unsigned acc = 0; for (int k = 0; k < 32; ++k) { key_start[k] = acc; acc += key_count[k]; } }
+            __syncthreads();
+            if (tid < take) { const unsigned pos = key_start[key] + rank; sorted_slot[pos] = q_slot[tid]; sorted_index[pos] = q_index[tid]; }
+            // what does not fit this round moves to the front of the queue (fewer than N entries)
+            const unsigned rest = q_n - take;
+            int r_slot = 0; unsigned r_index = 0; unsigned char r_key = 0;
+            if (tid < rest) { r_slot = q_slot[take + tid]; r_index = q_index[take + tid]; r_key = q_key[take + tid]; }
+            __syncthreads();
+            if (tid < rest) { q_slot[tid] = r_slot; q_index[tid] = r_index; q_key[tid] = r_key; }
+            q_n = rest;
+            bool died = false;
+            if (tid < take) {
+                const int slot = sorted_slot[tid];
+                const float4 o = B.ro[slot], d = B.rd[slot], tm = B.tm[slot];
+                int px, py, layer; slot_pixel(P, B, slot, px, py, layer);
+                const float2 hh = B.hit[slot];
+                SmallShade none; none.meta = 0;
+                died = wf_shade_entry<NOISE, true>(sc, cam, P, B, slot, px, py, o, d, tm, hh.x, __float_as_int(hh.y), none);
+                if (died) B.active[cur][sorted_index[tid]] = -1;     // stays in the list as a hole until the next compaction
+            }
+            wave_count_sub(B.counters + 0, died);
+            __syncthreads();                                         // sorted_* and the queue are free again
+        }
+        if (flush) break;
     }
-    bool died = false;
-    if (slot >= 0) {
-        const float4 o = B.ro[slot], d = B.rd[slot], tm = B.tm[slot];
-        int px, py, layer; slot_pixel(P, B, slot, px, py, layer);
-        const float2 hh = B.hit[slot];
-        SmallShade none; none.meta = 0;
-        died = wf_shade_entry<NOISE, true>(sc, cam, P, B, slot, px, py, o, d, tm, hh.x, __float_as_int(hh.y), none);
-        if (died) B.active[cur][i] = -1;                            // stays in the list as a hole until the next compaction
-    }
-    wave_count_sub(B.counters + 0, died);
 }
 
 // active[cur][0..n_list) -> active[cur^1][0..live): order kept inside a block, one atomic per block
@@ -421,7 +462,8 @@ hipError_t launch_wf_bounce(const SceneT<float> &sc, const CameraT<float> &cam, 
     else if (sc.media_kind == 1) hipLaunchKernelGGL((k_wf_extend<1, RTC_KIND_ALL>), dim3(blocks), dim3(kWfExtendBlock), lds, stream, args);
     else hipLaunchKernelGGL((k_wf_extend<2, RTC_KIND_ALL>), dim3(blocks), dim3(kWfExtendBlock), lds, stream, args);
     if (sc.n_general == 0) return hipGetLastError();               // every hit was shaded in extend's tail
-    const dim3 sgrid((n_list + kWfShadeBlock - 1) / kWfShadeBlock);
+    static const unsigned n_cus_shade = [] { int dev = 0, n = 256; if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return (unsigned)(n > 0 ? n : 256); }();
+    const dim3 sgrid(std::min((n_list + kWfShadeBlock - 1) / kWfShadeBlock, n_cus_shade));   // persistent: one 1024-thread workgroup per CU
     if (sc.tex_kinds & (1 << RTC_TEX_NOISE)) hipLaunchKernelGGL(k_wf_shade<true>, sgrid, dim3(kWfShadeBlock), 0, stream, sc, cam, p, b, cur, n_list);
     else hipLaunchKernelGGL(k_wf_shade<false>, sgrid, dim3(kWfShadeBlock), 0, stream, sc, cam, p, b, cur, n_list);
     return hipGetLastError();

@@ -15,9 +15,6 @@
 #include <vector>
 
 #include "kernels.h"
-#ifndef RT_BVH4
-#define RT_BVH4 0   // rt_core.hpp: 1 = the four-child-tree A/B build
-#endif
 // hip_runtime.h declares a class template named `texture` (legacy texture references); the host API's opaque
 // `struct texture` (reference name, texture.h:20) is renamed inside this translation unit only.
 #define texture rtc_host_texture
@@ -47,7 +44,7 @@ struct DevBuf {
 };
 
 template <typename R> struct DeviceTables {
-    DevBuf prims, bprims, ops, chains, materials, textures, lights, perlin_vec, perlin_perm, images, image_data, nodes, nodes4, leaf_prims, bleaves, leaf_shade, ref_steps, ref_boxes;
+    DevBuf prims, bprims, ops, chains, materials, textures, lights, perlin_vec, perlin_perm, images, image_data, nodes, leaf_prims, bleaves, leaf_shade, ref_steps, ref_boxes;
     SceneT<R> view;
     bool ready = false;
 };
@@ -72,11 +69,7 @@ template <typename R> hipError_t upload_tables(const FlatScene &fs, DeviceTables
     UP(perlin_vec, pvec); UP(perlin_perm, fs.perlin_perm); UP(images, fs.images); UP(image_data, fs.image_data); UP(leaf_prims, fs.leaf_prims);
     if (with_ref_steps) { UP(ref_steps, fs.ref_steps); UP(ref_boxes, fs.ref_boxes); }
     else {
-#if RT_BVH4   // A/B build (rt_core.hpp): the four-child table instead of the binary one
-        UP(nodes4, fs.nodes4);
-#else
         UP(nodes, fs.nodes);
-#endif
         UP(bleaves, fs.bleaves); UP(leaf_shade, fs.leaf_shade);
     }
 #undef UP
@@ -89,17 +82,12 @@ template <typename R> hipError_t upload_tables(const FlatScene &fs, DeviceTables
     v.lights = (const LightT<R> *)dt.lights.p; v.n_lights = (int)fs.lights.size();
     v.perlin_vec = (const R *)dt.perlin_vec.p; v.perlin_perm = (const int *)dt.perlin_perm.p;
     v.images = (const ImageDesc *)dt.images.p; v.image_data = (const unsigned char *)dt.image_data.p;
-    v.nodes = (const BvhNode *)dt.nodes.p; v.nodes4 = (const BvhNode4 *)dt.nodes4.p; v.leaf_prims = (const int *)dt.leaf_prims.p; v.n_nodes = (int)fs.nodes.size();
+    v.nodes = (const BvhNode *)dt.nodes.p; v.leaf_prims = (const int *)dt.leaf_prims.p; v.n_nodes = (int)fs.nodes.size();
     v.bleaves = (const BLeaf *)dt.bleaves.p; v.leaf_shade = (const SmallShade *)dt.leaf_shade.p;
     v.ref_steps = (const RefStep *)dt.ref_steps.p; v.ref_boxes = (const double *)dt.ref_boxes.p;
     v.n_ref_steps = with_ref_steps ? (int)fs.ref_steps.size() : 0;
     v.bvh_root = (fs.nodes.size() == 1 && fs.nodes[0].child1 == RTC_BVH_EMPTY) ? fs.nodes[0].child0 : 0;
-#if RT_BVH4
-    v.bvh_root = 0;   // the four-child step tests child != RTC_BVH_EMPTY itself
-    v.bvh_stack = fs.bvh_stack < 1 ? 1 : fs.bvh_stack;
-#else
     v.bvh_stack = fs.bvh_depth < 1 ? 1 : fs.bvh_depth;   // one entry per level; flatten / load refuse trees deeper than RTC_BVH_MAX_DEPTH: nothing is clamped here
-#endif
     v.n_media = fs.n_media;
     v.n_bleaves = (int)fs.bleaves.size();
     v.n_general = 0; for (const SmallShade &sh : fs.leaf_shade) v.n_general += (sh.meta & RTC_SF_GENERAL) != 0;
@@ -320,15 +308,6 @@ int rtc_scene_dump_bvh(const rtc_scene *scene, void *nodes16, int node_cap, void
     if (leaves16) std::memcpy(leaves16, fs.bleaves.data(), nl * sizeof(BLeaf));
     if (prim_of_slot) std::memcpy(prim_of_slot, fs.leaf_prims.data(), nl * sizeof(int));
     return (int)fs.bleaves.size();
-}
-
-int rtc_scene_dump_bvh4(const rtc_scene *scene, void *nodes32, int node_cap, int *stack_entries) {
-    if (!scene) return fail(RTC_ERR_ARG, "rtc_scene_dump_bvh4: null scene");
-    const FlatScene &fs = scene->flat;
-    static_assert(sizeof(BvhNode4) == 128, "table layout");
-    if (nodes32) std::memcpy(nodes32, fs.nodes4.data(), std::min((size_t)(node_cap > 0 ? node_cap : 0), fs.nodes4.size()) * sizeof(BvhNode4));
-    if (stack_entries) *stack_entries = fs.bvh_stack;
-    return (int)fs.nodes4.size();
 }
 
 // Every compute entry point: the scene has device tables, and they live on the calling thread's current device (a kernel

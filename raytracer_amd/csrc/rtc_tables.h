@@ -39,13 +39,6 @@ struct ImageDesc { int width, height; uint32_t offset, pad; };                  
 // `count` (1..8) consecutive slots of bleaves / leaf_prims starting at `first`.
 struct alignas(16) BvhNode { float lo0[3]; int child0; float hi0[3]; int count0; float lo1[3]; int child1; float hi1[3]; int count1; };
 enum { RTC_BVH_EMPTY = (int)0x80000000, RTC_BVH_MAX_DEPTH = 64 };
-// Four-child node of the RT_BVH4 A/B build (rt_core.hpp; the product traverses the binary table): collapsed from the binary tree on the host (flatten.cpp build_bvh4: the child
-// of larger surface area is replaced by its own two children until there are four).  One lane step tests four boxes from
-// one 112-byte fetch -- half as many DEPENDENT fetches per ray as the two-child node, which is what the 1M-sphere scene
-// waits for.  Component-major, so that one 16-byte load brings one plane of all four children; child refs as in BvhNode
-// (>= 0 inner node4 index, < 0 leaf run, RTC_BVH_EMPTY = no such child: never entered whatever its box says).
-struct alignas(128) BvhNode4 { float lox[4], loy[4], loz[4], hix[4], hiy[4], hiz[4]; int child[4]; int pad[4]; };
-enum { RTC_BVH_MAX_STACK = 64 };   // entries per lane the traversal stack may need (LDS: 256 B per entry and wave)
 inline int rtc_leaf_ref(int first, int count) { return ~((first << 3) | (count - 1)); }
 // Traversal leaf of the FP32 production BVH: 64 bytes, the size of a node, so a lane fetches "what it stands on" with the
 // same four 16-byte loads whether that is a node or a leaf.  Stored in BVH leaf order (slot s of bleaves is primitive
@@ -84,11 +77,11 @@ template <typename R> struct SceneT {
     const LightT<R> *lights; int n_lights;
     const R *perlin_vec;     const int *perlin_perm;   // per noise slot: 768 reals, 768 ints
     const ImageDesc *images; const unsigned char *image_data;
-    const BvhNode *nodes;    const BvhNode4 *nodes4;  const int *leaf_prims; int n_nodes;   // n_nodes == 0: brute-force loop over prims; nodes4: RT_BVH4 builds only
+    const BvhNode *nodes;    const int *leaf_prims; int n_nodes;   // n_nodes == 0: brute-force loop over prims
     const BLeaf *bleaves;                                          // FP32 production BVH only (NULL in the FP64 tables)
     const struct SmallShade *leaf_shade;                           // per leaf slot: everything shading needs of a resolved leaf, one 48-byte read
     int bvh_root;            // where a traversal starts: node 0, or the leaf run itself when the whole scene is one leaf (its node's second child is RTC_BVH_EMPTY and its box is never tested)
-    int bvh_stack;           // entries the traversal stack needs: the levels of the binary tree (RT_BVH4: max over paths of the sum of (children - 1))
+    int bvh_stack;           // entries the traversal stack needs: the levels of the binary tree
     const RefStep *ref_steps; const double *ref_boxes; int n_ref_steps;   // FP64 check path; boxes = min xyz, max xyz
     int n_media;             // media among prims (stochastic hits)
     int leaf_kinds;          // BVH leaves: bit 0 rects, bit 1 spheres, bit 2 moving spheres, bit 3 boxes (RTC_KIND_*, rt_core.hpp)

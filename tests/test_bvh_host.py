@@ -148,51 +148,6 @@ def test_bvh_structure_and_leaf_geometry(rtc, oracle_lib, name, arg):
         sc.close()
 
 
-@pytest.mark.parametrize("name,arg", [("book1", 0), ("final", 0), ("million", 40), ("box_field_smoke", 0)])
-def test_four_child_tree_is_the_binary_tree_collapsed(rtc, name, arg):
-    """flatten.cpp build_bvh4: the four-child tree of the RT_BVH4 A/B build (the product traverses the binary tree: the
-    four-child traversal measured 4-21 % slower).  Pre-order (a child lies behind its parent), every leaf run of the
-    binary tree referenced exactly once with the binary node's box, every inner node4 referenced by one parent, unused
-    child slots marked empty, and the reported stack need = max over root-to-leaf paths of the sum of (children - 1)."""
-    sc, cam, view = rtc.build_named_scene(name, arg=arg, host_only=True)
-    try:
-        nodes_u, leaves_u, prims = sc.dump_bvh()
-        n4_u, stack_entries = sc.dump_bvh4()
-        assert 0 < len(n4_u) <= len(nodes_u) and sc.bvh_info()["bytes"] == 64 * len(nodes_u) + 68 * len(leaves_u)
-        bi, bf = nodes_u.view(np.int32), nodes_u.view(np.float32)
-        want = {}                                                           # leaf ref -> (lo, hi) in the binary tree
-        for n in range(len(bi)):
-            for side in (0, 1):
-                c = int(bi[n, 3 + 8 * side])
-                if c < 0 and c != EMPTY:
-                    want[c] = (tuple(bf[n, 8 * side:8 * side + 3]), tuple(bf[n, 8 * side + 4:8 * side + 7]))
-        qi, qf = n4_u.view(np.int32), n4_u.view(np.float32)
-        got, parents = {}, np.zeros(len(qi), dtype=np.int64)
-        need, worst, fill = {0: 0}, 0, []
-        for n in range(len(qi)):                                            # pre-order: a node's own need is known when it is reached
-            kids = [k for k in range(4) if int(qi[n, 24 + k]) != EMPTY]
-            assert kids == list(range(len(kids))) and len(kids) >= 1        # the used slots come first
-            fill.append(len(kids))
-            here = need[n] + len(kids) - 1
-            worst = max(worst, here)
-            for k in kids:
-                c = int(qi[n, 24 + k])
-                box = (tuple(qf[n, [k, 4 + k, 8 + k]]), tuple(qf[n, [12 + k, 16 + k, 20 + k]]))
-                if c >= 0:
-                    assert n < c < len(qi)
-                    parents[c] += 1
-                    need[c] = here
-                else:
-                    assert c not in got
-                    got[c] = box
-        assert (parents[1:] == 1).all() and parents[0] == 0
-        assert got == want                                                   # same leaf runs, same boxes, each once
-        assert stack_entries == max(worst, 1) <= 64
-        assert np.mean(fill) > 2.5                                           # leaves of <= 2 records keep the bottom nodes from filling up
-    finally:
-        sc.close()
-
-
 def test_small_scenes_have_no_bvh(rtc):
     sc, cam, view = rtc.build_named_scene("cornell", host_only=True)
     try:

@@ -50,13 +50,15 @@ inline WfDiv wf_make_div(uint32_t d) {
     WfDiv r; r.shift = 30 + s; r.mul = (uint32_t)((((unsigned long long)1 << r.shift) + d - 1) / d);
     return r;
 }
+enum { WF_LIVE = 0, WF_CURSOR = 1, WF_NLIST = 2, WF_CUR = 3 };
 struct WfBuffers {
     float4 *ro, *rd, *tm, *sum;       // origin | time, direction | throughput.x, throughput.yz | sample + (depth << 24) | leaf slot
                                       // the ray starts on (int bits), radiance sum of the slot; the pixel follows from the slot
     float2 *hit;                      // t, leaf slot (int bits; -1 = miss) written by extend
     unsigned char *key;               // per LIST position, written by extend: regrouping key of a hit parked for k_wf_shade (material type * 4 + texture type), RTC_WF_KEY_DONE otherwise
     int *active[2];                   // slot lists (ping-pong across compactions); -1 = hole
-    unsigned *counters;               // 16 words: [0] live slots, [1] compaction cursor
+    unsigned *counters;               // 16 words, device-side control of the render (WF_*): live slots, compaction cursor, length and
+                                      // buffer index of the current slot list -- the host enqueues a fixed schedule and never reads them
     unsigned long long *stats;        // wf_stats_bytes(): 16 striped partial counters (rays, extend waves) behind one unused line; scene-wide like the pool
     unsigned long long *stats_out;    // [0] rays, [1] extend waves of the calling stream: k_wf_finish folds the stripes into them
     int n_slots, slots_per_layer, layers;
@@ -66,12 +68,11 @@ struct WfBuffers {
 size_t wf_bytes_per_slot();
 size_t wf_stats_bytes();
 hipError_t launch_wf_init(const CameraT<float> &cam, const RenderParams &p, const WfBuffers &b, hipStream_t stream);
-// one bounce: extend + shade over the first n_list entries of slot list `cur`
+// one bounce: extend (+ shade of the parked hits) over the current slot list, whose length and buffer index live in b.counters
 bool wf_lds_tables(const SceneT<float> &sc, size_t *lds_bytes);   // extend from LDS-resident node / leaf tables (small trees)?
-hipError_t launch_wf_bounce(const SceneT<float> &sc, const CameraT<float> &cam, const RenderParams &p, const WfBuffers &b,
-                            int cur, unsigned n_list, hipStream_t stream);
-// list `cur` -> list `cur ^ 1` without holes
-hipError_t launch_wf_compact(const WfBuffers &b, int cur, unsigned n_list, hipStream_t stream);
+hipError_t launch_wf_bounce(const SceneT<float> &sc, const CameraT<float> &cam, const RenderParams &p, const WfBuffers &b, hipStream_t stream);
+// current list -> the other list without holes, IF a quarter of it is holes (decided on the device)
+hipError_t launch_wf_compact(const WfBuffers &b, hipStream_t stream);
 hipError_t launch_wf_finish(const RenderParams &p, const WfBuffers &b, float4 *accum, hipStream_t stream);
 
 // ---- single rays and known-answer probes (kernels_probe.hip, kernels_small.hip) --------------------------------------

@@ -144,7 +144,7 @@ __device__ __forceinline__ bool wf_shade_entry(const SceneT<float> &sc, const Ca
 // dozen scalars of them, the tail (camera, render parameters, buffer pointers) fifty more, and with everything live across the loop
 // the kernels spilled up to 86 SGPRs to vector lanes.  wf_args_again() hands out the kernel-argument segment through a pointer the
 // compiler cannot see through, so what is read through it is (re)loaded by s_load where the tail stands -- behind the loop.
-struct WfArgs { SceneT<float> sc; CameraT<float> cam; RenderParams P; WfBuffers B; int cur; unsigned n_list; };
+struct WfArgs { SceneT<float> sc; CameraT<float> cam; RenderParams P; WfBuffers B; };
 __device__ __forceinline__ const WfArgs &wf_args_again() {
     const WfArgs __attribute__((address_space(4))) *p = (const WfArgs __attribute__((address_space(4))) *)__builtin_amdgcn_kernarg_segment_ptr();
     asm volatile("" : "+s"(p));
@@ -184,7 +184,8 @@ __global__ void __launch_bounds__(256) k_wf_init(CameraT<float> cam, RenderParam
         B.active[0][slot] = live ? slot : -1;
     }
     const int n = __syncthreads_count(live);                         // one atomic per block
-    if (threadIdx.x == 0 && n) atomicAdd(B.counters + 0, (unsigned)n);
+    if (threadIdx.x == 0 && n) atomicAdd(B.counters + WF_LIVE, (unsigned)n);
+    if (slot == 0) { B.counters[WF_NLIST] = (unsigned)B.n_slots; B.counters[WF_CUR] = 0u; B.counters[WF_CURSOR] = 0u; }
 }
 
 // counters: [0] live slots, [1] cursor of the compaction; stats (64-bit): [0] rays, [1] extend waves with a live lane
@@ -212,7 +213,10 @@ constexpr int kWfExtendBlock = RT_WF_EXTEND_BLOCK;
 #endif
 template <int MEDIA, int KINDS>
 __global__ void __launch_bounds__(kWfExtendBlock) __attribute__((amdgpu_waves_per_eu(MEDIA == 2 ? 6 : RT_WF_EXTEND_WAVES))) k_wf_extend(WfArgs a) {
-    const SceneT<float> &sc = a.sc; const RenderParams &P = a.P; const WfBuffers &B = a.B; const int cur = a.cur; const unsigned n_list = a.n_list;
+    const SceneT<float> &sc = a.sc; const RenderParams &P = a.P; const WfBuffers &B = a.B;
+    if (B.counters[WF_LIVE] == 0) return;                            // the render is over: the rest of the fixed bounce schedule drains at once
+    const unsigned n_list = B.counters[WF_NLIST]; const int cur = (int)B.counters[WF_CUR];   // the list as the last compaction left it
+    if (blockIdx.x * blockDim.x >= n_list) return;
     extern __shared__ int lds_stack[];                               // sc.bvh_stack entries per lane
     const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
     const int slot = i < n_list ? B.active[cur][i] : -1;
@@ -235,7 +239,7 @@ __global__ void __launch_bounds__(kWfExtendBlock) __attribute__((amdgpu_waves_pe
         const HitS h = bvh_closest_hit<KINDS>(sc, r, 0.001f, Mth<float>::inf(), stack, medium, src_slot);   // ray.c:56
         const WfArgs &t = wf_args_again();
         died = wf_extend_tail(t.sc, t.cam, t.P, t.B, slot, px, py, o, d, tm, h, key);
-        if (died) t.B.active[t.cur][i] = -1;                         // stays in the list as a hole until the next compaction
+        if (died) t.B.active[cur][i] = -1;                           // stays in the list as a hole until the next compaction
     }
     if (sc.n_general && i < n_list) B.key[i] = key;                  // by LIST position: k_wf_shade scans them with coalesced reads
     wave_count_sub(B.counters + 0, died);
@@ -257,7 +261,9 @@ __global__ void __launch_bounds__(kWfExtendBlock) __attribute__((amdgpu_waves_pe
 constexpr int kWfLdsBlock = 1024;
 template <int KINDS>
 __global__ void __launch_bounds__(kWfLdsBlock) __attribute__((amdgpu_waves_per_eu(8))) k_wf_extend_lds(WfArgs a) {
-    const SceneT<float> &sc = a.sc; const RenderParams &P = a.P; const WfBuffers &B = a.B; const int cur = a.cur; const unsigned n_list = a.n_list;
+    const SceneT<float> &sc = a.sc; const RenderParams &P = a.P; const WfBuffers &B = a.B;
+    if (B.counters[WF_LIVE] == 0) return;
+    const unsigned n_list = B.counters[WF_NLIST]; const int cur = (int)B.counters[WF_CUR];
     const int n_leaf_recs = sc.n_bleaves;
     extern __shared__ float4 lds_tab[];                              // nodes | leaves | stacks
     float4 *const node_tab = lds_tab, *const leaf_tab = lds_tab + 4 * sc.n_nodes;
@@ -298,7 +304,7 @@ __global__ void __launch_bounds__(kWfLdsBlock) __attribute__((amdgpu_waves_per_e
             const WfArgs &t = wf_args_again();
             int px, py, layer; slot_pixel(t.P, t.B, slot, px, py, layer);
             died = wf_extend_tail(t.sc, t.cam, t.P, t.B, slot, px, py, o, d, tm, h, key);
-            if (died) t.B.active[t.cur][i] = -1;
+            if (died) t.B.active[cur][i] = -1;
         }
         if (sc.n_general && i < n_list) B.key[i] = key;
         wave_count_sub(B.counters + 0, died);
@@ -321,8 +327,10 @@ __global__ void __launch_bounds__(kWfLdsBlock) __attribute__((amdgpu_waves_per_e
 // Only slot ids move; no global atomics; the order of the work is a function of the list alone.
 constexpr int kWfShadeBlock = 1024;
 template <bool NOISE>
-__global__ void __launch_bounds__(kWfShadeBlock) __attribute__((amdgpu_waves_per_eu(NOISE ? 5 : 6))) k_wf_shade(SceneT<float> sc, CameraT<float> cam, RenderParams P, WfBuffers B, int cur, unsigned n_list) {
+__global__ void __launch_bounds__(kWfShadeBlock) __attribute__((amdgpu_waves_per_eu(NOISE ? 5 : 6))) k_wf_shade(SceneT<float> sc, CameraT<float> cam, RenderParams P, WfBuffers B) {
     constexpr unsigned N = kWfShadeBlock;
+    if (B.counters[WF_LIVE] == 0) return;
+    const unsigned n_list = B.counters[WF_NLIST]; const int cur = (int)B.counters[WF_CUR];
     __shared__ int q_slot[2 * N];
     __shared__ unsigned q_index[2 * N];
     __shared__ unsigned char q_key[2 * N];
@@ -384,10 +392,20 @@ __global__ void __launch_bounds__(kWfShadeBlock) __attribute__((amdgpu_waves_per
     }
 }
 
-// active[cur][0..n_list) -> active[cur^1][0..live): order kept inside a block, one atomic per block
-__global__ void __launch_bounds__(1024) k_wf_compact(WfBuffers B, int cur, unsigned n_list) {
+// active[cur][0..n_list) -> active[cur^1][0..live): order kept inside a block, one atomic per block.  Launched at fixed points of the
+// bounce schedule; whether the list is worth squeezing -- a quarter of it holes -- is decided HERE, from the device's own counters,
+// so the host never waits for a count: every block takes the same decision, and k_wf_flip, the next kernel in the stream, takes it
+// once more and makes the new list current.
+__device__ __forceinline__ bool wf_worth_compacting(const unsigned *counters) {
+    const unsigned live = counters[WF_LIVE], n_list = counters[WF_NLIST];
+    return live != 0 && live < n_list - n_list / 4;
+}
+__global__ void __launch_bounds__(1024) k_wf_compact(WfBuffers B) {
     __shared__ unsigned wave_count[16];
     __shared__ unsigned block_base;
+    if (!wf_worth_compacting(B.counters)) return;
+    const unsigned n_list = B.counters[WF_NLIST]; const int cur = (int)B.counters[WF_CUR];
+    if (blockIdx.x * blockDim.x >= n_list) return;
     const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
     const int slot = i < n_list ? B.active[cur][i] : -1;
     const bool live = slot >= 0;
@@ -397,9 +415,13 @@ __global__ void __launch_bounds__(1024) k_wf_compact(WfBuffers B, int cur, unsig
     __syncthreads();
     unsigned before = 0, total = 0;
     for (int w = 0; w < 16; ++w) { const unsigned c = wave_count[w]; before += w < wave ? c : 0u; total += c; }
-    if (threadIdx.x == 0) block_base = total ? atomicAdd(B.counters + 1, total) : 0u;
+    if (threadIdx.x == 0) block_base = total ? atomicAdd(B.counters + WF_CURSOR, total) : 0u;
     __syncthreads();
     if (live) B.active[cur ^ 1][block_base + before + (unsigned)__builtin_popcountll(mask & ((1ull << lane) - 1ull))] = slot;
+}
+__global__ void k_wf_flip(WfBuffers B) {
+    if (wf_worth_compacting(B.counters)) { B.counters[WF_NLIST] = B.counters[WF_CURSOR]; B.counters[WF_CUR] ^= 1u; }
+    B.counters[WF_CURSOR] = 0;
 }
 
 __global__ void __launch_bounds__(256) k_wf_finish(RenderParams P, WfBuffers B, float4 *__restrict__ accum, const unsigned long long *__restrict__ stats,
@@ -444,16 +466,18 @@ hipError_t launch_wf_init(const CameraT<float> &cam, const RenderParams &p, cons
     hipLaunchKernelGGL(k_wf_init, dim3((unsigned)((b.n_slots + 255) / 256)), dim3(256), 0, stream, cam, p, b);
     return hipGetLastError();
 }
-hipError_t launch_wf_bounce(const SceneT<float> &sc, const CameraT<float> &cam, const RenderParams &p, const WfBuffers &b,
-                            int cur, unsigned n_list, hipStream_t stream) {
-    if (n_list == 0) return hipSuccess;
-    const unsigned blocks = (n_list + kWfExtendBlock - 1) / kWfExtendBlock;
+hipError_t launch_wf_bounce(const SceneT<float> &sc, const CameraT<float> &cam, const RenderParams &p, const WfBuffers &b, hipStream_t stream) {
+    // the grid covers every slot: the list only shrinks, by how much is known on the device alone (counters[WF_NLIST]); workgroups
+    // behind its end return at once
+    const unsigned n_max = (unsigned)b.n_slots;
+    if (n_max == 0) return hipSuccess;
+    const unsigned blocks = (n_max + kWfExtendBlock - 1) / kWfExtendBlock;
     const size_t lds = (size_t)sc.bvh_stack * kWfExtendBlock * sizeof(int);
     size_t lds_tab = 0;
-    const WfArgs args{sc, cam, p, b, cur, n_list};
+    const WfArgs args{sc, cam, p, b};
+    static const unsigned n_cus = [] { int dev = 0, n = 256; if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return (unsigned)(n > 0 ? n : 256); }();
     if (wf_lds_tables(sc, &lds_tab)) {
-        static const unsigned n_cus = [] { int dev = 0, n = 256; if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return (unsigned)(n > 0 ? n : 256); }();
-        const unsigned lblocks = std::min((n_list + kWfLdsBlock - 1) / kWfLdsBlock, 2u * n_cus);   // persistent: two workgroups per CU
+        const unsigned lblocks = std::min((n_max + kWfLdsBlock - 1) / kWfLdsBlock, 2u * n_cus);   // persistent: two workgroups per CU
         if (sc.leaf_kinds == RTC_KIND_SPHERE) hipLaunchKernelGGL((k_wf_extend_lds<RTC_KIND_SPHERE>), dim3(lblocks), dim3(kWfLdsBlock), lds_tab, stream, args);
         else hipLaunchKernelGGL((k_wf_extend_lds<RTC_KIND_ALL>), dim3(lblocks), dim3(kWfLdsBlock), lds_tab, stream, args);
     }
@@ -462,16 +486,14 @@ hipError_t launch_wf_bounce(const SceneT<float> &sc, const CameraT<float> &cam, 
     else if (sc.media_kind == 1) hipLaunchKernelGGL((k_wf_extend<1, RTC_KIND_ALL>), dim3(blocks), dim3(kWfExtendBlock), lds, stream, args);
     else hipLaunchKernelGGL((k_wf_extend<2, RTC_KIND_ALL>), dim3(blocks), dim3(kWfExtendBlock), lds, stream, args);
     if (sc.n_general == 0) return hipGetLastError();               // every hit was shaded in extend's tail
-    static const unsigned n_cus_shade = [] { int dev = 0, n = 256; if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return (unsigned)(n > 0 ? n : 256); }();
-    const dim3 sgrid(std::min((n_list + kWfShadeBlock - 1) / kWfShadeBlock, n_cus_shade));   // persistent: one 1024-thread workgroup per CU
-    if (sc.tex_kinds & (1 << RTC_TEX_NOISE)) hipLaunchKernelGGL(k_wf_shade<true>, sgrid, dim3(kWfShadeBlock), 0, stream, sc, cam, p, b, cur, n_list);
-    else hipLaunchKernelGGL(k_wf_shade<false>, sgrid, dim3(kWfShadeBlock), 0, stream, sc, cam, p, b, cur, n_list);
+    const dim3 sgrid(std::min((n_max + kWfShadeBlock - 1) / kWfShadeBlock, n_cus));   // persistent: one 1024-thread workgroup per CU
+    if (sc.tex_kinds & (1 << RTC_TEX_NOISE)) hipLaunchKernelGGL(k_wf_shade<true>, sgrid, dim3(kWfShadeBlock), 0, stream, sc, cam, p, b);
+    else hipLaunchKernelGGL(k_wf_shade<false>, sgrid, dim3(kWfShadeBlock), 0, stream, sc, cam, p, b);
     return hipGetLastError();
 }
-hipError_t launch_wf_compact(const WfBuffers &b, int cur, unsigned n_list, hipStream_t stream) {
-    hipError_t e = hipMemsetAsync(b.counters + 1, 0, sizeof(unsigned), stream);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_wf_compact, dim3((n_list + 1023) / 1024), dim3(1024), 0, stream, b, cur, n_list);
+hipError_t launch_wf_compact(const WfBuffers &b, hipStream_t stream) {
+    hipLaunchKernelGGL(k_wf_compact, dim3(((unsigned)b.n_slots + 1023) / 1024), dim3(1024), 0, stream, b);
+    hipLaunchKernelGGL(k_wf_flip, dim3(1), dim3(1), 0, stream, b);
     return hipGetLastError();
 }
 hipError_t launch_wf_finish(const RenderParams &p, const WfBuffers &b, float4 *accum, hipStream_t stream) {

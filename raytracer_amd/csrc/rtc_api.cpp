@@ -160,11 +160,13 @@ struct rtc_scene {
     DevBuf ray_counter;                        // wavefront only: striped statistics + queue counters, ordered across streams by wf_done like the pool
     DevBuf wf_pool; size_t wf_slots_cap = 0;   // wavefront path-slot state, grown on demand
     hipEvent_t wf_done = nullptr;              // end of the last wavefront render's final accumulate: the pool is shared by all streams
+    hipStream_t wf_stream[4] = {nullptr, nullptr, nullptr, nullptr};   // streams of the parts a wavefront render is split into (part 0 runs on the caller's)
+    hipEvent_t wf_fork = nullptr, wf_part_done[4] = {nullptr, nullptr, nullptr, nullptr};
     DevBuf small_pairs, small_groups, small_spheres, small_shade, small_xforms, small_boxes;
     SmallScene small{};   // n_leaves == 0: not eligible
     std::map<void *, StreamState> streams;
     std::mutex mu;
-    ~rtc_scene() { if (wf_done) (void)hipEventDestroy(wf_done); for (auto &kv : streams) { if (kv.second.ev0) (void)hipEventDestroy(kv.second.ev0); if (kv.second.ev1) (void)hipEventDestroy(kv.second.ev1); } }
+    ~rtc_scene() { if (wf_done) (void)hipEventDestroy(wf_done); if (wf_fork) (void)hipEventDestroy(wf_fork); for (int k = 0; k < 4; k++) { if (wf_part_done[k]) (void)hipEventDestroy(wf_part_done[k]); if (wf_stream[k]) (void)hipStreamDestroy(wf_stream[k]); } for (auto &kv : streams) { if (kv.second.ev0) (void)hipEventDestroy(kv.second.ev0); if (kv.second.ev1) (void)hipEventDestroy(kv.second.ev1); } }
 };
 
 extern "C" {
@@ -194,7 +196,7 @@ const char *rtc_device_name(void) {
 static rtc_scene *upload_scene(rtc_scene *s, const char *who) {
     if (hipGetDevice(&s->device) != hipSuccess) { g_error = std::string(who) + ": no current HIP device"; delete s; return nullptr; }
     hipError_t e = upload_tables<float>(s->flat, s->f32, false);
-    std::vector<unsigned char> zero(wf_stats_bytes() + 64, 0);   // [0] rays, [1] wave bounce-iterations, striped wavefront statistics, 16 queue counters
+    std::vector<unsigned char> zero(4 * (wf_stats_bytes() + 64), 0);   // per part of a wavefront render: striped statistics, 16 control words (kernels.h WF_*)
     if (e == hipSuccess) e = s->ray_counter.upload(zero.data(), zero.size());
     if (e == hipSuccess && s->flat.small_ok) {
         const FlatScene &fs = s->flat;
@@ -411,13 +413,23 @@ static int check_settings(const rtc_settings *st) {
     return RTC_OK;
 }
 
-// Wavefront driver (kernels_wf.hip): init, then extend + shade per bounce until no slot is live, then the accumulate.
-// The live count is read back every few bounces, so this path returns only when the work has been ENQUEUED AND RUN up to
-// the final accumulate (which is left in flight on `stream`).
-static int render_wavefront(rtc_scene *s, const CameraT<float> &camf, const RenderParams &p, float4 *accum, unsigned long long *stats_out, hipStream_t stream) {
-    const int spp = p.s_end - p.s_begin;
-    if (spp <= 0) return RTC_OK;
-    const long long per_layer = (long long)p.n_tiles * 64;
+// Wavefront driver (kernels_wf.hip): init, a FIXED schedule of bounces (extend + shade), a compaction every eight of them, then the
+// accumulate.  Nothing is read back: the length of the slot list, which of its two buffers is current, whether a compaction is worth
+// it and whether anything is still alive are device-side state (WfBuffers::counters), and a kernel of the schedule that finds no
+// live slot returns at once -- so the call only ENQUEUES, like the small-scene path, and the caller's stream is free to carry the
+// next frame or a reduce behind it.
+// The samples are split into up to three parts that run the same schedule on streams of their own, side by side: extend is bound
+// by VALU issue and fetch latency, the tail of every launch runs on a thinning set of waves, and a second and third part fill what
+// one leaves idle (final scene 1024^2 x 256 spp: 116 -> ... ms, 1M spheres: 48 -> ... ms).  Each part owns a share of
+// the path-slot pool and its own counters; their accumulates run in part order, so the image does not depend on timing.
+enum { RTC_WF_MAX_PARTS = 4 };
+static int render_wavefront(rtc_scene *s, const CameraT<float> &camf, const RenderParams &p_all, float4 *accum, unsigned long long *stats_out, hipStream_t stream) {
+    const int spp_all = p_all.s_end - p_all.s_begin;
+    if (spp_all <= 0) return RTC_OK;
+    const long long per_layer = (long long)p_all.n_tiles * 64;
+    int n_parts = spp_all >= 48 ? 3 : (spp_all >= 16 ? 2 : 1);
+    if (const char *e = std::getenv("RTC_WF_PARTS")) { const int v = std::atoi(e); if (v >= 1 && v <= RTC_WF_MAX_PARTS) n_parts = v; }   // A/B knob
+    if (n_parts > spp_all) n_parts = spp_all;
     // Slots per pixel ("layers").  A slot walks through its samples one after the other, so a render lasts as many bounces
     // as the UNLUCKIEST slot needs; with ~8 samples per slot that is <= 8 * max_depth bounces of large launches instead of
     // hundreds of bounces whose tail runs on a few live slots (final scene 1024^2 x 256 spp: 411 ms at 1M slots, 227 ms at
@@ -425,56 +437,82 @@ static int render_wavefront(rtc_scene *s, const CameraT<float> &camf, const Rend
     // the cap for experiments.
     long long max_slots = 32ll << 20;
     if (const char *e = std::getenv("RTC_WF_SLOTS")) { const long long v = std::atoll(e); if (v > 0) max_slots = v; }
-    long long layers = (spp + 7) / 8;
-    if (layers * per_layer > max_slots) layers = max_slots / per_layer;
-    if (layers * per_layer < (1ll << 20)) layers = ((1ll << 20) + per_layer - 1) / per_layer;   // small images: at least 1M slots
-    if (layers > spp) layers = spp;
-    if (layers < 1) layers = 1;
-    const long long n_slots = per_layer * layers;
-    if (n_slots > (1ll << 30)) return fail(RTC_ERR_ARG, "image too large for the wavefront path");
+    struct Part { RenderParams p; long long layers, n_slots; WfBuffers b; long long iterations; };
+    Part part[RTC_WF_MAX_PARTS];
+    long long total_slots = 0;
+    for (int k = 0; k < n_parts; ++k) {
+        Part &P = part[k];
+        P.p = p_all;
+        P.p.s_begin = p_all.s_begin + (int)((long long)spp_all * k / n_parts);
+        P.p.s_end = p_all.s_begin + (int)((long long)spp_all * (k + 1) / n_parts);
+        const int spp = P.p.s_end - P.p.s_begin;
+        long long layers = (spp + 7) / 8;
+        if (layers * per_layer > max_slots / n_parts) layers = max_slots / n_parts / per_layer;
+        if (layers * per_layer < (1ll << 20) / n_parts) layers = ((1ll << 20) / n_parts + per_layer - 1) / per_layer;   // small images: at least 1M slots in all
+        if (layers > spp) layers = spp;
+        if (layers < 1) layers = 1;
+        P.layers = layers; P.n_slots = per_layer * layers;
+        P.iterations = ((spp + layers - 1) / layers) * (long long)(P.p.max_depth > 0 ? P.p.max_depth : 1);
+        total_slots += P.n_slots;
+    }
+    if (total_slots > (1ll << 30)) return fail(RTC_ERR_ARG, "image too large for the wavefront path");
     const size_t per_slot = wf_bytes_per_slot();
     // The previous render's final accumulate may still be in flight on ANOTHER stream and reads the pool this render is about
     // to overwrite (this call returns with that kernel enqueued, not finished): order this stream behind it.
     if (!s->wf_done) HIP_TRY(hipEventCreateWithFlags(&s->wf_done, hipEventDisableTiming));
     else HIP_TRY(hipStreamWaitEvent(stream, s->wf_done, 0));
-    if ((size_t)n_slots > s->wf_slots_cap) {
+    if ((size_t)total_slots > s->wf_slots_cap) {
         if (s->wf_pool.p) { HIP_TRY(hipEventSynchronize(s->wf_done)); HIP_TRY(hipStreamSynchronize(stream)); (void)hipFree(s->wf_pool.p); s->wf_pool.p = nullptr; s->wf_slots_cap = 0; }
-        if (hipMalloc(&s->wf_pool.p, (size_t)n_slots * per_slot + 256) != hipSuccess) { s->wf_pool.p = nullptr; return fail(RTC_ERR_NOMEM, "wavefront path-slot state does not fit in device memory"); }
-        s->wf_slots_cap = (size_t)n_slots;
+        if (hipMalloc(&s->wf_pool.p, (size_t)total_slots * per_slot + 256 * RTC_WF_MAX_PARTS) != hipSuccess) { s->wf_pool.p = nullptr; return fail(RTC_ERR_NOMEM, "wavefront path-slot state does not fit in device memory"); }
+        s->wf_slots_cap = (size_t)total_slots;
     }
-    WfBuffers b; std::memset(&b, 0, sizeof b);
-    char *base = (char *)s->wf_pool.p;
-    const size_t n = (size_t)n_slots;
-    b.ro = (float4 *)base; base += n * sizeof(float4);
-    b.rd = (float4 *)base; base += n * sizeof(float4);
-    b.tm = (float4 *)base; base += n * sizeof(float4);
-    b.sum = (float4 *)base; base += n * sizeof(float4);
-    b.hit = (float2 *)base; base += n * sizeof(float2);
-    b.active[0] = (int *)base; base += n * sizeof(int);
-    b.active[1] = (int *)base; base += n * sizeof(int);
-    b.key = (unsigned char *)base; base += n;
-    b.stats = (unsigned long long *)s->ray_counter.p; b.stats_out = stats_out;
-    b.counters = (unsigned *)((char *)s->ray_counter.p + wf_stats_bytes());
-    b.n_slots = (int)n_slots; b.slots_per_layer = (int)per_layer; b.layers = (int)layers;
-    b.quad = layers % 4 == 0;
-    b.div_group = wf_make_div((uint32_t)(b.quad ? 4 * per_layer : per_layer)); b.div_tiles_x = wf_make_div((uint32_t)p.tiles_x);
-    HIP_TRY(launch_wf_init(camf, p, b, stream));
-    const long long max_iterations = ((spp + layers - 1) / layers) * (long long)(p.max_depth > 0 ? p.max_depth : 1) + 1;
-    unsigned n_list = (unsigned)n_slots;
-    int cur = 0;
-    long long it = 0;
-    for (;;) {
-        unsigned live = 0;
-        HIP_TRY(hipMemcpyAsync(&live, b.counters, sizeof live, hipMemcpyDeviceToHost, stream));
-        HIP_TRY(hipStreamSynchronize(stream));
-        if (live == 0 || it >= max_iterations) break;
-        if (live < n_list - n_list / 4) {                               // a quarter of the list is holes: squeeze them out
-            HIP_TRY(launch_wf_compact(b, cur, n_list, stream));
-            cur ^= 1; n_list = live;
+    for (int k = 1; k < n_parts; ++k)
+        if (!s->wf_stream[k]) {
+            HIP_TRY(hipStreamCreateWithFlags(&s->wf_stream[k], hipStreamNonBlocking));
+            HIP_TRY(hipEventCreateWithFlags(&s->wf_part_done[k], hipEventDisableTiming));
         }
-        for (int k = 0; k < 8 && it < max_iterations; ++k, ++it) HIP_TRY(launch_wf_bounce(s->f32.view, camf, p, b, cur, n_list, stream));
+    if (!s->wf_fork) { HIP_TRY(hipEventCreateWithFlags(&s->wf_fork, hipEventDisableTiming)); HIP_TRY(hipEventCreateWithFlags(&s->wf_part_done[0], hipEventDisableTiming)); }
+    char *base = (char *)s->wf_pool.p;
+    for (int k = 0; k < n_parts; ++k) {
+        WfBuffers &b = part[k].b; std::memset(&b, 0, sizeof b);
+        const size_t n = (size_t)part[k].n_slots;
+        b.ro = (float4 *)base; base += n * sizeof(float4);
+        b.rd = (float4 *)base; base += n * sizeof(float4);
+        b.tm = (float4 *)base; base += n * sizeof(float4);
+        b.sum = (float4 *)base; base += n * sizeof(float4);
+        b.hit = (float2 *)base; base += n * sizeof(float2);
+        b.active[0] = (int *)base; base += n * sizeof(int);
+        b.active[1] = (int *)base; base += n * sizeof(int);
+        b.key = (unsigned char *)base; base += (n + 255) / 256 * 256;
+        char *ctl = (char *)s->ray_counter.p + (size_t)k * (wf_stats_bytes() + 64);
+        b.stats = (unsigned long long *)ctl; b.stats_out = stats_out;
+        b.counters = (unsigned *)(ctl + wf_stats_bytes());
+        b.n_slots = (int)n; b.slots_per_layer = (int)per_layer; b.layers = (int)part[k].layers;
+        b.quad = part[k].layers % 4 == 0;
+        b.div_group = wf_make_div((uint32_t)(b.quad ? 4 * per_layer : per_layer)); b.div_tiles_x = wf_make_div((uint32_t)p_all.tiles_x);
     }
-    HIP_TRY(launch_wf_finish(p, b, accum, stream));
+    // fork: the parts' streams start behind everything the caller's stream holds so far
+    hipStream_t st[RTC_WF_MAX_PARTS];
+    st[0] = stream;
+    if (n_parts > 1) HIP_TRY(hipEventRecord(s->wf_fork, stream));
+    for (int k = 1; k < n_parts; ++k) { st[k] = s->wf_stream[k]; HIP_TRY(hipStreamWaitEvent(st[k], s->wf_fork, 0)); }
+    for (int k = 0; k < n_parts; ++k) HIP_TRY(launch_wf_init(camf, part[k].p, part[k].b, st[k]));
+    long long longest = 0;
+    for (int k = 0; k < n_parts; ++k) longest = std::max(longest, part[k].iterations);
+    for (long long it = 0; it < longest; ++it)                       // round robin, so that the parts' kernels reach the GPU interleaved
+        for (int k = 0; k < n_parts; ++k) {
+            if (it >= part[k].iterations) continue;
+            if (it && it % 8 == 0) HIP_TRY(launch_wf_compact(part[k].b, st[k]));
+            HIP_TRY(launch_wf_bounce(s->f32.view, camf, part[k].p, part[k].b, st[k]));
+        }
+    // join: the accumulates run in part order (each adds to the same pixels), the last one on the caller's stream
+    for (int k = n_parts - 1; k >= 1; --k) {
+        if (k < n_parts - 1) HIP_TRY(hipStreamWaitEvent(st[k], s->wf_part_done[k + 1], 0));
+        HIP_TRY(launch_wf_finish(part[k].p, part[k].b, accum, st[k]));
+        HIP_TRY(hipEventRecord(s->wf_part_done[k], st[k]));
+    }
+    if (n_parts > 1) HIP_TRY(hipStreamWaitEvent(stream, s->wf_part_done[1], 0));
+    HIP_TRY(launch_wf_finish(part[0].p, part[0].b, accum, stream));
     HIP_TRY(hipEventRecord(s->wf_done, stream));
     return RTC_OK;
 }

@@ -211,7 +211,7 @@ print("accepted", acc, "refused", ref)
 def test_scene_loader_mutation_fuzz_under_sanitizers(tmp_path):
     """tools/fuzz/scene_fuzz.cpp: random payload words of valid scene files overwritten (small integers, sign bits, huge values), the CRC
     brought up to date so that the damage reaches validate_flat_scene, and whatever loads walked by the host code that runs after
-    a load (four-child tree, light matching) -- compiled with ASan + UBSan.  A gap in the validator shows up as an out-of-bounds read."""
+    a load (light matching) -- compiled with ASan + UBSan.  A gap in the validator shows up as an out-of-bounds read."""
     import shutil
     import subprocess
     if not shutil.which("g++"):

@@ -1,7 +1,7 @@
 // Mutation fuzz of the scene-file loader (development aid): random payload bytes of a valid scene file are overwritten -- biased
 // towards small integers, sign bits and huge values, the things an index or a count can be -- the header's CRC is brought up to
 // date so that the damage reaches validate_flat_scene(), and whatever loads is walked by the host code that runs after a load
-// (the four-child tree, the light matching).  Built with ASan + UBSan: a validator gap shows up as an out-of-bounds read.
+// (the light matching).  Built with ASan + UBSan: a validator gap shows up as an out-of-bounds read.
 //   g++ -O1 -g -std=c++17 -fsanitize=address,undefined -static-libasan -I../../include -I../../raytracer_amd/csrc/host \
 //       scene_fuzz.cpp ../../raytracer_amd/csrc/host/scene_io.cpp ../../raytracer_amd/csrc/host/flatten.cpp -lz -lpthread
 #include <zlib.h>
@@ -37,7 +37,7 @@ int main(int argc, char **argv) {
         std::memcpy(b.data() + 24, &crc, 4);
         FILE *o = std::fopen(tmp, "wb"); if (!o) return 2; std::fwrite(b.data(), 1, b.size(), o); std::fclose(o);
         FlatScene fs; std::string err;
-        if (load_flat_scene(tmp, fs, err)) { loaded++; build_bvh4(fs); mark_small_lights(fs); } else refused++;
+        if (load_flat_scene(tmp, fs, err)) { loaded++; mark_small_lights(fs); } else refused++;
     }
     std::printf("loaded %d, refused %d\n", loaded, refused);
     return 0;

@@ -15,9 +15,15 @@ the device buffers, the streams and the process group.
 The JSON line also carries
   roofline      FP32 VALU roofline of the path-tracing kernel: algorithmic FLOP/ray (tests/flop_model.py)
                 x rays per launch / HIP-event kernel time measured by the library on the launch stream;
-  cpu_baseline  the CPU oracle (a port pinned byte-for-byte to the compiled reference) on all host cores with a
-                per-thread counter RNG -- the "fair" CPU row -- on a bounded sample of the same workload, plus the
-                compiled reference itself on one thread (its rand() is a global lock: more threads are slower).
+  cpu_baseline  the three CPU rows of SURVEY 8(d), each on a bounded sample of the same workload: (iii) the CPU oracle (a port pinned
+                byte-for-byte to the compiled reference) on all host cores with a per-thread counter RNG -- the "fair" row, the one
+                `cpu_baseline` and the speed-up quote; (ii) `cpu_reference_1t`, the compiled reference on one thread; (i)
+                `cpu_reference_as_shipped`, the compiled reference's own loop under its `omp parallel for` over 16 row chunks with
+                the one process-wide rand() (main.c:132-160, utils.h:23: a global lock, more threads are slower);
+  probe_ms      the small-scene kernel's one-sample tile-cost probe + sort: paid by the FIRST frame of a (camera, image size) and cached
+                per stream afterwards, i.e. outside every timed step when there is a warm-up frame -- printed so that it is not hidden;
+  reduce_ms     (N > 1) one reduce of the float4[W*H] accumulators to rank 0 on its own, median of 5, measured behind the timed
+                region: what a step would pay if the frame pipeline did not overlap it with the next render.
 """
 import argparse
 import json
@@ -37,6 +43,7 @@ from raytracer_amd import dist as rdist  # noqa: E402
 
 WIDTH, HEIGHT, DEPTH = 1920, 1080, 10
 SPP_PER_GPU = 256
+OTHER_REPS = 5                     # measured renders of each `other_configs` entry (median reported)
 # tests/flop_model.py, Cornell 16:9 (DESIGN.md "Roofline"): minimal-algorithm FLOP per closest-hit query incl. shading
 ALGO_FLOP_PER_RAY = 218.6
 PEAK_FP32_VALU_TFLOPS = 157.3     # MI355X_MICROARCH.md: 256 CU x 4 SIMD x 32 lanes x 2 (FMA) x 2.4 GHz
@@ -141,6 +148,14 @@ def cpu_baseline(budget_s=15.0):
         out["cpu_reference_1t"] = dict(value=w * rows * s / dt / 1e6, unit="Msamples/s", cores=1, kind="reference", seconds=round(dt, 2),
                                        sample=f"compiled 03_FullTracer (oracle/_ref/libref03.so), its own loop main.c:132-160, "
                                               f"{w}x{rows} px x {s} spp, 1 thread, rand()")
+        if hasattr(r.lib, "hx_render_refloop_omp"):
+            shipped_threads = 16                                # main.c:132: THREADS = 4 * 4 chunks, one OpenMP thread each where the host has them
+            t0 = time.perf_counter()
+            r.render_refloop_omp(w, h, s, DEPTH, threads=shipped_threads, seed=1)
+            dt = time.perf_counter() - t0
+            out["cpu_reference_as_shipped"] = dict(value=w * rows * s / dt / 1e6, unit="Msamples/s", cores=shipped_threads, kind="reference", seconds=round(dt, 2),
+                                                   sample=f"compiled 03_FullTracer, `#pragma omp parallel for` over its 16 row chunks (main.c:137), every thread on "
+                                                          f"the one locked rand() (utils.h:23), {w}x{rows} px x {s} spp")
     return out
 
 
@@ -150,14 +165,18 @@ def other_config(scene, W, H, spp, dev):
     sc, cam, view = ra.build_named_scene(scene, arg=1000 if scene == "million" else 0, aspect=W / H)
     build_s = time.perf_counter() - t0
     acc = rdist.new_accum(H, W, dev)
-    st = None
-    for rep in range(2):
+    runs = []
+    for rep in range(1 + OTHER_REPS):                            # one warm-up (allocates the path-slot pool), then the measured renders
         acc.zero_()
         stream = rdist.render_into(sc, cam, ra.Settings(W, H, spp, view.max_depth, view.integrator, seed=rep), acc)
         torch.cuda.synchronize()
-        st = sc.stats(stream)
+        if rep:
+            runs.append(sc.stats(stream))
+    runs.sort(key=lambda r: r["kernel_ms"])
+    st = runs[len(runs) // 2]                                     # the median render (median of >= 5 after one warm-up)
     out = {"workload": f"{WORKLOADS[scene]}, {W}x{H}, {spp} spp, depth {view.max_depth}", "scene_build_s": round(build_s, 3),
-           "ms": st["kernel_ms"], "msamples_per_s": st["samples"] / st["kernel_ms"] * 1e-3, "mrays_per_s": st["rays"] / st["kernel_ms"] * 1e-3,
+           "ms": st["kernel_ms"], "ms_all": [round(r["kernel_ms"], 3) for r in runs], "renders": len(runs), "statistic": "median",
+           "msamples_per_s": st["samples"] / st["kernel_ms"] * 1e-3, "mrays_per_s": st["rays"] / st["kernel_ms"] * 1e-3,
            "rays_per_sample": st["rays"] / st["samples"], "roofline": scene_roofline(scene, st["rays"], st["kernel_ms"])}
     sc.close()
     return out
@@ -215,6 +234,7 @@ def main():
     accum = rdist.new_accum(HEIGHT, WIDTH, dev)
     rgb8 = torch.empty((HEIGHT, WIDTH, 3), dtype=torch.uint8, device=dev)
     kernel_ms, rays_total, kernel_used, lane_fill = [], 0, [0], [0.0]
+    first_frame_ms = [None]                                      # kernel time of the very first frame: it pays the tile-cost probe + sort
 
     def tonemap(acc, frame):                                     # rank 0 holds the frame's sum over all ranks
         if rank == 0:
@@ -238,6 +258,8 @@ def main():
         # Reading the counters waits for the render kernel's end event (a host sync).  At N = 1 that is every step -- the
         # roofline's kernel time is the average over the timed launches; at N > 1 a sync per step would stop rank r from
         # enqueueing its next render while the reduce of this one is in flight, so only the last timed step is read.
+        if i == 0 and not dist_on:
+            first_frame_ms[0] = scene.stats(stream)["kernel_ms"]
         if record and (not dist_on or i == a.warmup + a.steps - 1):
             st = scene.stats(stream)
             kernel_ms.append(st["kernel_ms"])
@@ -271,6 +293,18 @@ def main():
     else:
         rays_all, k_ms = t[1].item(), t[2].item()
 
+    # one reduce on its own (N > 1), behind the timed region: the cost the frame pipeline hides behind the next render
+    reduce_ms = None
+    if dist_on:
+        probe_acc = rdist.new_accum(HEIGHT, WIDTH, dev)
+        times = []
+        for _ in range(6):
+            torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+            t_r = time.perf_counter()
+            rdist.reduce_accum(probe_acc)
+            torch.cuda.synchronize()
+            times.append((time.perf_counter() - t_r) * 1e3)
+        reduce_ms = float(np.median(times[1:]))
     if rank == 0:
         samples_all = WIDTH * HEIGHT * a.spp * world * a.steps
         rays_per_launch = rays_all / max(1, a.steps * world)
@@ -293,6 +327,9 @@ def main():
                        "width": WIDTH, "height": HEIGHT, "spp_per_gpu": a.spp, "global_spp": a.spp * world, "max_depth": depth,
                        "sharding": f"samples/{world}", "collective": "reduce(sum) of float4[W*H] to rank 0" if world > 1 else "none"},
             "mrays_per_s": rays_all / elapsed / 1e6, "rays_per_sample": rays_all / samples_all,
+            "rays_source": "last timed step x steps, summed over ranks (a counter read is a host sync: one per run at N > 1)" if dist_on else "every timed step",
+            "probe_ms": (max(0.0, first_frame_ms[0] - k_ms) if first_frame_ms[0] is not None and kernel_used[0] == 2 and a.warmup > 0 else None),
+            "reduce_ms": reduce_ms,
             "roofline": {"bound": "valu", "achieved": achieved, "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP32_VALU_TFLOPS, "traffic": traffic["bytes"] if traffic and not traffic["stale"] else None,
                          "traffic_source": traffic, "kernel": SMALL_KERNEL_NAME if kernel_used[0] == 2 else "k_pathtrace_mega",

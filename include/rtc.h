@@ -6,6 +6,7 @@
  * points are what a maintainer binds IN PLACE OF that loop; each one names the reference code it
  * replaces.  Plain C symbols, opaque handles, int status (0 ok, <0 error; text via rtc_last_error()),
  * no C++/torch types; the caller owns every buffer it passes.  INTEGRATION.md shows the call sequence.
+ * (What only tests call -- table dumps, inspection, known-answer probes -- is declared in rtc_test.h, which is not installed.)
  *
  * Device selection: every call acts on the CURRENT HIP device of the calling thread (one process per
  * GPU; under torch.distributed that is LOCAL_RANK's device).  There is no CPU fallback: with no usable
@@ -83,28 +84,6 @@ rtc_scene *rtc_scene_load_host(const char *path);
 void rtc_scene_free(rtc_scene *scene);
 /* Number of flattened leaf primitives (visit order of the reference's traversal = primitive id). */
 int  rtc_scene_num_prims(const rtc_scene *scene);
-/* Flattened leaf table for inspection: per leaf 16 doubles = reference hittable_type (hittable.h:42-52), material type,
- * geometry (sphere: c,r | moving sphere: c0,c1,t0,t1,r | rect: x0,x1,y0,y1,z0,z1,k,axis | medium: -1/density) from slot 2,
- * slot 12 = number of translate/rotate wrappers, slot 13 = flip_face parity. */
-int  rtc_scene_dump_leaves(const rtc_scene *scene, double *out16, int cap);
-/* Shape of the production BVH (inspection; no reference counterpart: the reference's tree is bvh_node_constructor's,
- * hittable.c:163-215): out4 = inner nodes, leaf slots, levels, bytes of nodes + traversal leaves.  All 0 for a scene of
- * at most 64 leaves (brute-force loop). */
-int  rtc_scene_bvh_info(const rtc_scene *scene, long long *out4);
-/* The small-scene pack (scenes of <= 64 rect / sphere leaves): out8 = eligible, pairs, object spaces, slab-tested boxes, spheres,
- * light pdfs fused into the intersection (every light-list entry is a world-space leaf of the pack), rects and spheres that
- * carry a light's pdf.  Inspection only; no reference counterpart. */
-int  rtc_scene_small_info(const rtc_scene *scene, int *out8);
-/* How the wavefront path intersects this scene's rays (BVH scenes; inspection, no reference counterpart): out4 = [0] 1 if the node and
- * leaf tables are staged in LDS (small trees without media, at most 80 KB with the stacks; RTC_WF_LDS_TABLES=0 in the environment
- * turns it off), [1] bytes of LDS per workgroup in that case, [2] inner nodes, [3] leaf records.  Needs device tables. */
-int  rtc_scene_extend_info(const rtc_scene *scene, int *out4);
-/* The production BVH itself, for structural checks on a machine without a GPU: nodes16 = per inner node 16 words (float
- * lo0[3], int child0, float hi0[3], int count0, the same for child 1; child < 0 encodes a leaf run ~((first << 3) | (count-1))),
- * leaves16 = per leaf slot 16 words (15 floats of world-space geometry + meta), prim_of_slot = primitive id per leaf slot.
- * Any pointer may be NULL; the caps are in entries.  Returns the number of leaf slots. */
-int  rtc_scene_dump_bvh(const rtc_scene *scene, void *nodes16, int node_cap, void *leaves16, int *prim_of_slot, int leaf_cap);
-
 /* FP64, no-FMA closest hit for n host rays (7 doubles each: orig, dir, time): bit-exact replacement of
  * hittable_list_hit(world, r, tmin, tmax, &rec) (hittable_list.c:125-143).  prim_id[i] = -1 on miss.
  * The kernel replays the reference's own traversal (list order; bvh_node_hit's left-then-right recursion over the tree
@@ -120,22 +99,16 @@ int rtc_first_hit_f64(const rtc_scene *scene, const double *rays7, size_t n, dou
 int rtc_primary_first_hit_f64(const rtc_scene *scene, const camera *cam, const double *st2, const double *lens3,
                               size_t n, double tmin, double tmax, int32_t *prim_id, double *t, double *rays7_out);
 
-/* The PRODUCTION traversal on its own: hittable_list_hit (hittable_list.c:125-143) as the FP32 path tracer executes it
- * (brute-force leaf loop up to 64 leaves, flattened SoA BVH with a per-lane LDS stack above), rays converted to float.
- * Ties between leaves go to the highest primitive id; media are skipped.  Agreement with rtc_first_hit_f64 is a
- * tolerance statement (tests/test_gpu_first_hit.py), not a bit-exact one. */
-int rtc_first_hit_f32(const rtc_scene *scene, const double *rays7, size_t n, double tmin, double tmax,
-                      int32_t *prim_id, float *t);
-
 /* The hot path: replaces the pixel/sample loop of 03 main.c:137-160 (camera_get_ray + ray_color + sum).
  * accum_rgba is W*H float4 = (sum R, sum G, sum B, sample count), row j=0 at the BOTTOM like the reference's
  * pixel index (main.c:157); the call ADDS to it, so successive calls with disjoint sample ranges accumulate
  * progressively.  rtc_render_device takes a DEVICE pointer (e.g. a torch tensor's data_ptr) and enqueues on
  * `stream` (a hipStream_t, NULL = default stream) without synchronising; rtc_render takes a HOST buffer.
- * EXCEPTION: the wavefront pipeline (kernel 3, the automatic choice for every scene flattened into a BVH) runs a host loop
- * that reads the live-path count back every 8 bounces: the call BLOCKS the calling thread (holding the scene's mutex) until
- * the last bounce has run and returns with only the final accumulate in flight on `stream`.  Small scenes (kernel 2) and the
- * megakernel (kernel 1) only enqueue. */
+ * Every kernel only enqueues: the wavefront pipeline (kernel 3, the automatic choice for every scene flattened into a BVH) puts a
+ * fixed schedule of bounces on `stream` and on up to two more streams the scene owns (the samples are split into parts that run
+ * side by side; they fork from `stream` and join it again before the call's last kernel), and whatever the host used to read back
+ * -- the length of the path list, whether to compact it, whether anything is alive -- is decided on the device.  What follows
+ * the call on `stream` (the next frame, a tonemap, a collective) is ordered behind the whole render. */
 int rtc_render_device(const rtc_scene *scene, const camera *cam, const rtc_settings *settings,
                       float *accum_rgba_device, void *stream);
 int rtc_render(const rtc_scene *scene, const camera *cam, const rtc_settings *settings, float *accum_rgba_host);
@@ -173,22 +146,6 @@ int rtc_render_stats(const rtc_scene *scene, void *stream, rtc_stats *out);
  * general bounce loop (the one kernel = 1 renders with) on the current device; the host ray_color of raytracer.h is this
  * call with n = 1 and one sample. */
 int rtc_ray_colors(const rtc_scene *scene, const double *rays7, size_t n, const rtc_settings *settings, double *rgb_sum);
-
-/* TEST-ONLY known-answer probe: evaluates, on the device and for n supplied inputs, the functions the production kernels
- * call, so that they can be compared with the reference's outputs for the same inputs (tests/golden/unit_vectors.npz).
- * Doubles in and out (converted to the kernels' FP32 on the device).  `what`:
- *   0 Philox4x32-7 block of (pixel, sample, tag, seed lo, seed hi) -> 4 raw words: counter = (pixel, sample, tag, seed lo),
- *     key = ("RTC1", seed hi)                                                              (replaces rand(), utils.h:23)
- *   1 light-list pdf, general kernels: origin(3) dir(3) -> pdf       (hittable_list.c:165-172, hittable.c:760-788)
- *   2 the same as the small-scene kernel computes it (unit direction, folded hit tests)
- *   3 cosine pdf = lambertian scattering pdf: normal(3) dir(3) -> pdf (pdf.c:100-103, material.c:205-208)
- *   4 reflectance: cosine, ref_idx -> r                               (material.c:142)
- *   5 refract: uv(3) n(3) eta -> dir(3)                               (vec3.c:44-50)
- *   6 light sample, general kernels: origin(3) pick r1 r2 -> dir(3)   (hittable.c:821-848; the reference draws r1, r2 from rand())
- *   7 the same, small-scene kernel (a basis of its own around the cone axis: same law, other azimuth)
- *   8 glass direction, general kernels: dir(3) n(3) front_face ir xi -> dir(3)   (material.c:144-157; xi replaces random_double())
- *   9 the same, small-scene kernel (takes the direction normalised) */
-int rtc_kat(const rtc_scene *scene, int what, const double *in, size_t n, double *out);
 
 /* write_color (ray.c:35-47): rgb/count -> sqrt -> clamp [0,0.999] -> *256 -> u8, for every pixel, on device.
  * rgb_u8 is W*H*3, same row order as accum (flip at PNG time like main.c:170).  NaN and negative sums map to 0

@@ -209,6 +209,31 @@ int hx_render_refloop(int W, int H, int spp, int depth, unsigned char *pixels) {
     return 0;
 }
 
+/* the same loop AS SHIPPED: `#pragma omp parallel for` over the 16 row chunks (03 main.c:137, 02 main.c:416), every thread drawing from
+ * the one process-wide rand() (utils.h:23; glibc's is lock-protected: more threads are SLOWER).  Timing row only: the
+ * image depends on the interleaving of the draws. */
+int hx_render_refloop_omp(int W, int H, int spp, int depth, int threads, unsigned char *pixels) {
+    const int THREADS = 4 * 4;
+    int step = floor(H / THREADS);
+    #pragma omp parallel for num_threads(threads)
+    for (int k = 0; k < THREADS; ++k)
+        for (int sj = step - 1; sj >= 0; --sj) {
+            int j = sj + (k * step);
+            for (int i = 0; i < W; ++i) {
+                color pc = {0, 0, 0};
+                for (int s = 0; s < spp; ++s) {
+                    double u = ((double)i + random_double()) / (double)(W - 1);
+                    double v = ((double)j + random_double()) / (double)(H - 1);
+                    ray r = camera_get_ray(g_cam, u, v);
+                    color c = hx_ray_color(&r, depth);
+                    pc.x += c.x; pc.y += c.y; pc.z += c.z;
+                }
+                write_color(pixels, &pc, spp, (i + (j * W)) * 3);
+            }
+        }
+    return 0;
+}
+
 /* ---- unit probes for pure functions ------------------------------------------------------ */
 int hx_unit_rect_hit(const double *rp /*x0,x1,y0,y1,z0,z1,k,axis*/, int n, const double *rays7, double tmin, double tmax, double *rec12) {
     material *m = material_dielectric_new(1.5);

@@ -53,7 +53,7 @@ class RtcStats(C.Structure):
 
 SCENES = dict(simple=0, cornell=1, final=2, book1=3, cornell02=4, cornell_smoke=5, two_spheres=6, two_perlin=7,
               simple_light=8, book2_random=9, million=10, earth=11, final_earth=12, box_field=13, box_field_smoke=14)
-EARTHMAP = os.path.join(os.path.dirname(_HERE), "tests", "golden", "earthmap.jpg")   # the reference's images/earthmap.jpg, 1024x512
+EARTHMAP = os.path.join(_HERE, "assets", "earthmap.jpg")   # the reference's images/earthmap.jpg, 1024x512: package data, installed to share/raytracer_amd
 
 _P = C.c_void_p
 _dp = C.POINTER(C.c_double)

@@ -194,16 +194,18 @@ RT_DEV HitT<R> closest_hit_ref(const SceneT<R> &sc, const RayT<R> &r, R tmin, R 
 // Same closest hit from the flattened BVH (rtc_tables.h BvhNode / BLeaf).  Any visiting order gives the same t; ties are
 // broken explicitly -- the leaf with the highest visit-order index (primitive id) wins, which is what the reference's
 // left-then-right scan produces.
-// Slab test of one child box: entry distance in tn; boxes are padded outward at build time and the extra slack covers
-// the rounding of this test itself.
-RT_DEV bool slab_f32(const float *lo, const float *hi, V3<float> noi, V3<float> inv, float tmin, float tmax, float &tn) {
-    // (lo - o) / d as one FMA per plane: lo * inv + noi with noi = -o * inv (bvh_begin).  Against (lo - o) * inv this
-    // moves the planes by up to |o| * 2^-24, the resolution of the FP32 ray origin itself; inv is finite (bvh_begin).
-    const float x0 = __builtin_fmaf(lo[0], inv.x, noi.x), x1 = __builtin_fmaf(hi[0], inv.x, noi.x);
-    const float y0 = __builtin_fmaf(lo[1], inv.y, noi.y), y1 = __builtin_fmaf(hi[1], inv.y, noi.y);
-    const float z0 = __builtin_fmaf(lo[2], inv.z, noi.z), z1 = __builtin_fmaf(hi[2], inv.z, noi.z);
-    tn = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), tmin));
-    const float tf = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fminf(fmaxf(z0, z1), tmax));
+// Slab test of one child box given as centre c and half-extent h (BvhNodeCH): entry distance in tn.  Per axis m = c * inv + noi
+// (noi = -o * inv, bvh_begin) is the parameter of the box centre, the planes lie h |inv| before and behind it -- nine FMAs and no
+// per-axis min / max (4 SIMD-cycles each on this part against 2.2 for an FMA).  Boxes are padded outward at build and upload time
+// and the extra slack covers the rounding of this test itself; against (lo - o) * inv the planes move by up to |o| * 2^-24, the
+// resolution of the FP32 ray origin itself; inv is finite (bvh_begin).
+RT_DEV bool slab_f32(const float *c, const float *h, V3<float> noi, V3<float> inv, float tmin, float tmax, float &tn) {
+    const float mx = __builtin_fmaf(c[0], inv.x, noi.x), my = __builtin_fmaf(c[1], inv.y, noi.y), mz = __builtin_fmaf(c[2], inv.z, noi.z);
+    const float ax = fabsf(inv.x), ay = fabsf(inv.y), az = fabsf(inv.z);                 // (source modifiers: no instructions)
+    const float x0 = __builtin_fmaf(-h[0], ax, mx), y0 = __builtin_fmaf(-h[1], ay, my), z0 = __builtin_fmaf(-h[2], az, mz);
+    const float x1 = __builtin_fmaf(h[0], ax, mx), y1 = __builtin_fmaf(h[1], ay, my), z1 = __builtin_fmaf(h[2], az, mz);
+    tn = fmaxf(fmaxf(x0, y0), fmaxf(z0, tmin));
+    const float tf = fminf(fminf(x1, y1), fminf(z1, tmax));
     return !(tn > tf * 1.0000001f + 1e-7f);
 }
 // Traversal stack: an LDS column per lane (entry e of lane l lives at base[e * stride + l]: consecutive lanes hit
@@ -292,9 +294,9 @@ RT_DEV void bvh_begin(BvhTrav &s, const RayT<float> &r, float tmax, int src_slot
     s.h.t = tmax; s.h.prim = -1; s.h.slot = -1; s.cur = root; s.src_slot = src_slot;
 }
 template <typename Stack>
-RT_DEV void bvh_node_step(const BvhNode &nd, BvhTrav &s, float tmin, Stack &stack) {
+RT_DEV void bvh_node_step(const BvhNodeCH &nd, BvhTrav &s, float tmin, Stack &stack) {
     float n0, n1;
-    const bool h0 = slab_f32(nd.lo0, nd.hi0, s.noi, s.inv, tmin, s.h.t, n0), h1 = slab_f32(nd.lo1, nd.hi1, s.noi, s.inv, tmin, s.h.t, n1);
+    const bool h0 = slab_f32(nd.c0, nd.h0, s.noi, s.inv, tmin, s.h.t, n0), h1 = slab_f32(nd.c1, nd.h1, s.noi, s.inv, tmin, s.h.t, n1);
     const bool both = h0 & h1, first0 = h0 & ((n0 <= n1) | !h1);   // the only hit child, or the nearer of two
     if (both) stack.push(first0 ? nd.child1 : nd.child0);
     s.cur = first0 ? nd.child0 : nd.child1;
@@ -342,9 +344,9 @@ RT_DEV void bvh_trip_tab(const SceneT<float> &sc, const float4 *node_tab, const 
     float4 q0 = ptr[0], q1 = ptr[1], q2 = ptr[2], q3 = ptr[3];
     asm volatile("" : "+v"(q0.x), "+v"(q1.x), "+v"(q2.x), "+v"(q3.x));   // pins the four loads here, ahead of both arms
     if (node) {
-        BvhNode nd;
-        nd.lo0[0] = q0.x; nd.lo0[1] = q0.y; nd.lo0[2] = q0.z; nd.child0 = __float_as_int(q0.w); nd.hi0[0] = q1.x; nd.hi0[1] = q1.y; nd.hi0[2] = q1.z;
-        nd.lo1[0] = q2.x; nd.lo1[1] = q2.y; nd.lo1[2] = q2.z; nd.child1 = __float_as_int(q2.w); nd.hi1[0] = q3.x; nd.hi1[1] = q3.y; nd.hi1[2] = q3.z;
+        BvhNodeCH nd;
+        nd.c0[0] = q0.x; nd.c0[1] = q0.y; nd.c0[2] = q0.z; nd.child0 = __float_as_int(q0.w); nd.h0[0] = q1.x; nd.h0[1] = q1.y; nd.h0[2] = q1.z;
+        nd.c1[0] = q2.x; nd.c1[1] = q2.y; nd.c1[2] = q2.z; nd.child1 = __float_as_int(q2.w); nd.h1[0] = q3.x; nd.h1[1] = q3.y; nd.h1[2] = q3.z;
         bvh_node_step(nd, s, tmin, stack);
     } else {
         BLeaf lf;

@@ -14,10 +14,17 @@
  * Appendix B.  Scenes that the reference builds with rand() draw from rand() in
  * the same order, so srand(1) + build reproduces the reference's geometry.
  */
+#ifdef RT_PRODUCT_BUILD          /* librtc.so only: the library looks for its image asset next to itself (dladdr) */
+#ifndef _GNU_SOURCE
+#define _GNU_SOURCE
+#endif
+#include <dlfcn.h>
+#endif
 #ifdef RT_API_HEADER
 #include RT_API_HEADER
 #endif
 #include <math.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -91,10 +98,34 @@ static hittable_list *scene_cornell(hittable_list *lights, rt_scene_view *v) {
 }
 #endif
 
-/* Image asset of the earth scenes.  The reference names "images/earthmap.jpg" relative to its working directory
- * (02 main.c:159); here the path is settable, and the default is the fixture that travels with this repository. */
-static char g_rt_image_path[1024] = "tests/golden/earthmap.jpg";
+/* Image asset of the earth scenes.  The reference names "images/earthmap.jpg" relative to its working directory (02 main.c:159).
+ * Here the file is a datum of the library: rt_scene_set_image_path() names it explicitly; otherwise $RT_EARTHMAP, then
+ * <directory of librtc.so>/../share/raytracer_amd/earthmap.jpg (`make install` puts it there), then <directory of librtc.so>/assets/
+ * earthmap.jpg (this source tree: raytracer_amd/assets/). */
+static char g_rt_image_path[1024] = "";
 void rt_scene_set_image_path(const char *path) { if (path) { strncpy(g_rt_image_path, path, sizeof g_rt_image_path - 1); g_rt_image_path[sizeof g_rt_image_path - 1] = 0; } }
+static char *rt_image_path(void) {
+    if (g_rt_image_path[0]) return g_rt_image_path;
+    static char found[1100];
+    const char *env = getenv("RT_EARTHMAP");
+    if (env && env[0]) { snprintf(found, sizeof found, "%s", env); return found; }
+#ifdef RT_PRODUCT_BUILD
+    Dl_info info;
+    if (dladdr((const void *)&rt_scene_set_image_path, &info) && info.dli_fname) {
+        char dir[1024]; snprintf(dir, sizeof dir, "%s", info.dli_fname);
+        char *slash = strrchr(dir, '/');
+        if (slash) *slash = 0; else snprintf(dir, sizeof dir, ".");
+        const char *tails[2] = {"/../share/raytracer_amd/earthmap.jpg", "/assets/earthmap.jpg"};
+        for (int k = 0; k < 2; k++) {
+            snprintf(found, sizeof found, "%s%s", dir, tails[k]);
+            FILE *f = fopen(found, "rb");
+            if (f) { fclose(f); return found; }
+        }
+    }
+#endif
+    snprintf(found, sizeof found, "earthmap.jpg");            /* texture_image_init reports the failure like the reference (texture.c:67) */
+    return found;
+}
 
 /* 02 main.c:230-289 -- Book-2 final scene.  rand() order: 400 box heights, BVH nodes,
  * perlin tables, 3000 sphere coordinates, BVH nodes. */
@@ -123,7 +154,7 @@ static hittable_list *scene_final(hittable_list *lights, rt_scene_view *v, int w
     texture *marble = texture_noise_init_scaled(5);
     hittable_sphere_new(objects, sv3(220, 280, 300), 80, material_lambertian_new(marble));
     if (with_earth) { /* BASELINE config 3 names an earth-map globe; the reference's final_scene has none: book position */
-        texture *earth = texture_image_init(g_rt_image_path);
+        texture *earth = texture_image_init(rt_image_path());
         if (!earth) return NULL;
         hittable_sphere_new(objects, sv3(400, 200, 400), 100, material_lambertian_new(earth));
     }
@@ -268,7 +299,7 @@ static hittable_list *scene_perlin(int with_light, rt_scene_view *v) {
 /* 02 main.c:157-163 with the camera of its switch case 4 (:344-350) -- one globe with the earth map */
 static hittable_list *scene_earth(rt_scene_view *v) {
     hittable_list *world = hittable_list_new(1024);
-    texture *earth = texture_image_init(g_rt_image_path);
+    texture *earth = texture_image_init(rt_image_path());
     if (!earth) return NULL;
     hittable_sphere_new(world, sv3(0, 0, 0), 2, material_lambertian_new(earth));
     view_book(v, 20, 0.0); v->integrator = 1; v->max_depth = 8;

@@ -37,7 +37,7 @@ hipError_t launch_pathtrace_small(const SmallScene &ss, const SceneT<float> &sc,
 // Production FP32 traversal alone (brute-force loop or flattened BVH), one lane per ray; media skipped.
 hipError_t launch_first_hit_f32(const SceneT<float> &sc, const float *rays7, size_t n, float tmin, float tmax, int32_t *prim_id, float *t, hipStream_t stream);
 hipError_t launch_tonemap_u8(const float4 *accum, int n_pixels, unsigned char *rgb, hipStream_t stream);
-hipError_t launch_accum_add(float4 *dst, const float4 *src, size_t n, hipStream_t stream);   // dst += src
+hipError_t launch_accum_add(float4 *dst, const float4 *const *src, int n_src, size_t n, hipStream_t stream);   // dst += src[0] + ... + src[n_src - 1], in that order (n_src <= 63)
 
 // ---- wavefront path tracer for BVH scenes (kernels_wf.hip) ----------------------------------------------------------
 // Path-slot state in HBM, SoA.  Slot s of layer k = s / slots_per_layer renders samples s_begin + k, + layers, ... of ONE

@@ -130,20 +130,25 @@ __global__ void __launch_bounds__(256) k_tonemap_u8(const float4 *__restrict__ a
     }
 }
 
-// dst += src over n float4 (rtc_render_multi: the accumulators of the other devices, added on the root in device order)
-__global__ void __launch_bounds__(256) k_accum_add(float4 *__restrict__ dst, const float4 *__restrict__ src, size_t n) {
+// dst += src[0] + src[1] + ... over n float4, added in that order (rtc_render_multi: the accumulators of the other handles, staged on the
+// root device, in handle order -- the sum does not depend on which device finished first)
+struct AccumSources { const float4 *src[63]; int count; };
+__global__ void __launch_bounds__(256) k_accum_add(float4 *__restrict__ dst, AccumSources s, size_t n) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    float4 a = dst[i]; const float4 b = src[i];
-    a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    float4 a = dst[i];
+    for (int k = 0; k < s.count; ++k) { const float4 b = s.src[k][i]; a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
     dst[i] = a;
 }
 
 }  // namespace
 
-hipError_t launch_accum_add(float4 *dst, const float4 *src, size_t n, hipStream_t stream) {
-    if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_accum_add, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, dst, src, n);
+hipError_t launch_accum_add(float4 *dst, const float4 *const *src, int n_src, size_t n, hipStream_t stream) {
+    if (n == 0 || n_src <= 0) return hipSuccess;
+    if (n_src > 63) return hipErrorInvalidValue;
+    AccumSources s; s.count = n_src;
+    for (int k = 0; k < 63; ++k) s.src[k] = k < n_src ? src[k] : nullptr;
+    hipLaunchKernelGGL(k_accum_add, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, dst, s, n);
     return hipGetLastError();
 }
 hipError_t launch_pathtrace_mega(const SceneT<float> &sc, const CameraT<float> &cam, const RenderParams &p,

@@ -30,11 +30,6 @@
 #ifndef RT_SMALL_WAVES
 #define RT_SMALL_WAVES 7
 #endif
-// RT_SMALL_FMA_SLAB=0: A/B build with the box slab planes as (k - o) * inv (two instructions per plane) instead of one FMA
-// (measured: the FMA form is 0.9 % faster, 17.98 -> 17.83 ms)
-#ifndef RT_SMALL_FMA_SLAB
-#define RT_SMALL_FMA_SLAB 1
-#endif
 
 namespace {
 
@@ -49,8 +44,6 @@ RT_DEV f3 xform_dir(const SmallXform &x, f3 d) {
 }
 RT_DEV f3 rcp3(f3 d) { return f3mk(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z)); }
 
-typedef float v2f __attribute__((ext_vector_type(2)));
-
 // rect_hit (hittable.c:494-506) for the two rects of a SmallPair, ray already split into the run's normal (on, in = 1/dn)
 // and in-plane (oab, dab) parts.  All range tests fold into ONE compare: the largest violation
 //   max(lo - p, p - hi, tmin - t, t - tbest) <= 0
@@ -61,13 +54,9 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 // A rect that is also an entry of the lights list (P.f[12] / P.f[13] = 1 / area, flatten.cpp mark_small_lights; a wave-uniform
 // branch) adds its pdf for THIS ray to `pdf` on the way: hittable_pdf_value (hittable.c:772-788) is this very plane test with
 // tmin 1e-4 and no upper bound, value t^2 |1/d_n| / area for a unit direction (small_light_pdf_one below is the stand-alone form).
-// RT_SMALL_SCALAR_PAIR=0: A/B build with the two in-plane axes of a rect test in packed FP32 instructions (v_pk_fma_f32 ...), the
-// round-1 form.  A packed instruction issues in 1.4x the time of a plain one (tools/ubench/valu_rates) and every run pays six
-// moves to build the aligned register pairs: the plain form below is 1-2 % faster on the headline render (17.95 -> 17.57 ms).
-#ifndef RT_SMALL_SCALAR_PAIR
-#define RT_SMALL_SCALAR_PAIR 1
-#endif
-#if RT_SMALL_SCALAR_PAIR
+// (Round 1 did the two in-plane axes of a rect test in packed FP32 instructions -- v_pk_fma_f32 ...: a packed instruction issues in 1.4x the
+// time of a plain one (tools/ubench/valu_rates) and every run paid six moves to build the aligned register pairs; the plain form
+// below measured 1-2 % faster on the headline render, 17.95 -> 17.57 ms, and the packed one was removed in round 3.)
 template <bool PDF>
 RT_DEV void small_rect(float k, float lo_a, float lo_b, float hi_a, float hi_b, int id, float inv_area, float on, float in, float oa, float da, float ob, float db,
                        float tmin, int src, SmallHit &h, float &pdf) {
@@ -88,55 +77,17 @@ RT_DEV void small_run(const SmallScene &ss, int first, int count, float on, floa
             small_rect<PDF>(P.f[1], P.f[6], P.f[7], P.f[8], P.f[9], __float_as_int(P.f[11]), P.f[13], on, in, oa, da, ob, db, tmin, src, h, pdf);
     }
 }
-#else
-template <bool PDF>
-RT_DEV void small_pair(const SmallPair &P, float on, float in, v2f oab, v2f dab, float tmin, int src, SmallHit &h, float &pdf) {
-    const v2f k = {P.f[0], P.f[1]};
-    const int id0 = __float_as_int(P.f[10]), id1 = __float_as_int(P.f[11]);
-    const v2f t = (k - on) * in;
-    {
-        const v2f p = oab + dab * t.x;
-        const v2f lo = {P.f[2], P.f[3]}, hi = {P.f[4], P.f[5]};
-        const v2f vl = lo - p, vh = p - hi;
-        const float outside = fmaxf(fmaxf(vl.x, vl.y), fmaxf(vh.x, vh.y));
-        const float viol = fmaxf(outside, fmaxf(tmin - t.x, t.x - h.t));
-        const bool hit = (viol <= 0.0f) & (id0 != src);
-        h.t = hit ? t.x : h.t; h.leaf = hit ? id0 : h.leaf;
-        if (PDF && P.f[12] != 0.0f) pdf += fmaxf(outside, 0.0001f - t.x) <= 0.0f ? (t.x * t.x) * (fabsf(in) * P.f[12]) : 0.0f;
-    }
-    if (id1 >= 0) {   // wave-uniform (a scalar compare): the run had an odd number of rects and this is its padding
-        const v2f p = oab + dab * t.y;
-        const v2f lo = {P.f[6], P.f[7]}, hi = {P.f[8], P.f[9]};
-        const v2f vl = lo - p, vh = p - hi;
-        const float outside = fmaxf(fmaxf(vl.x, vl.y), fmaxf(vh.x, vh.y));
-        const float viol = fmaxf(outside, fmaxf(tmin - t.y, t.y - h.t));
-        const bool hit = (viol <= 0.0f) & (id1 != src);
-        h.t = hit ? t.y : h.t; h.leaf = hit ? id1 : h.leaf;
-        if (PDF && P.f[13] != 0.0f) pdf += fmaxf(outside, 0.0001f - t.y) <= 0.0f ? (t.y * t.y) * (fabsf(in) * P.f[13]) : 0.0f;
-    }
-}
-template <bool PDF>
-RT_DEV void small_run(const SmallScene &ss, int first, int count, float on, float in, float oa, float da, float ob, float db, float tmin, int src, SmallHit &h, float &pdf) {
-    const v2f oab = {oa, ob}, dab = {da, db};
-    for (int p = first; p < first + count; ++p) small_pair<PDF>(ss.pairs[p], on, in, oab, dab, tmin, src, h, pdf);   // wave-uniform: one s_load_dwordx16
-}
-#endif
 // box_hit (hittable.c:521-523 = the list scan over the sides) as one slab test, also for a box with openings: the surface is entered at the largest
 // near-plane parameter and left at the smallest far-plane parameter; a ray that starts inside (or on) the box hits the
 // exit face.  The face gives the leaf id, so shading sees the same record as after six rect tests.
 // A ray that starts on a face (src) cannot hit that face again (rt_core.hpp box_leaf_t): not as the entry, not as the exit.
 RT_DEV void small_box(const SmallBox &B, f3 o, f3 inv, float tmin, int src, SmallHit &h) {
-#if RT_SMALL_FMA_SLAB   // (k - o) / d as one FMA per plane, k * inv + (-o * inv) (what slab_f32 does for the BVH boxes): the planes move by
-                        // up to |o| 2^-24, the resolution of the FP32 origin itself
+    // (k - o) / d as one FMA per plane, k * inv + (-o * inv) (what slab_f32 does for the BVH boxes): the planes move by up to
+    // |o| 2^-24, the resolution of the FP32 origin itself; 0.9 % faster than (k - o) * inv (17.98 -> 17.83 ms, round 2)
     const f3 noi = f3mk(-o.x * inv.x, -o.y * inv.y, -o.z * inv.z);
     const float x0 = __builtin_fmaf(B.lo[0], inv.x, noi.x), x1 = __builtin_fmaf(B.hi[0], inv.x, noi.x);
     const float y0 = __builtin_fmaf(B.lo[1], inv.y, noi.y), y1 = __builtin_fmaf(B.hi[1], inv.y, noi.y);
     const float z0 = __builtin_fmaf(B.lo[2], inv.z, noi.z), z1 = __builtin_fmaf(B.hi[2], inv.z, noi.z);
-#else
-    const float x0 = (B.lo[0] - o.x) * inv.x, x1 = (B.hi[0] - o.x) * inv.x;
-    const float y0 = (B.lo[1] - o.y) * inv.y, y1 = (B.hi[1] - o.y) * inv.y;
-    const float z0 = (B.lo[2] - o.z) * inv.z, z1 = (B.hi[2] - o.z) * inv.z;
-#endif
     const float nx = fminf(x0, x1), ny = fminf(y0, y1), nz = fminf(z0, z1);
     const float fx = fmaxf(x0, x1), fy = fmaxf(y0, y1), fz = fmaxf(z0, z1);
     const float t_in = fmaxf(fmaxf(nx, ny), nz), t_out = fminf(fminf(fx, fy), fz);
@@ -295,11 +246,26 @@ RT_DEV f3 small_light_sample(const SceneT<float> &sc, int pick, f3 o, float r1, 
 // intersection (flatten.cpp mark_small_lights); the stand-alone light-pdf loop is then not even compiled in.
 // (Two more variants were built, measured and taken out again -- the paths of a workgroup regrouped by material through LDS, +32 %;
 // one camera Philox block per sample pair, +2.5 %: DESIGN.md 3.1, profiles/r02a_regroup; the code is in the history up to 9791647.)
+// The kernel's arguments are ONE struct so that the parts of the kernel that run rarely -- the refill of the primary-ray buffers,
+// the epilogue -- can read theirs again where they stand: small_args_again() hands out the kernel-argument segment through a
+// pointer the compiler cannot see through (s_load where it is used), instead of twenty camera and image constants held in SGPRs
+// across the bounce loop next to the table pointers, the Philox key and the mixture weights.  The headline variant spilled 14
+// SGPRs to vector lanes before (LENS variants 21-24), none now.
+struct SmallArgs {
+    SmallScene ss; SceneT<float> sc; CameraT<float> cam; RenderParams P;
+    float4 *accum; unsigned long long *counters; const int *tile_perm; int *tile_cost; float4 *partial; int log2_chunks;
+};
+// (`when` = a wave-uniform value that changes from use to use: the asm statement is NOT volatile -- a volatile one counts as a write
+// to memory, after which hipcc fetches the scene records of the bounce loop with vector loads instead of s_load -- so what keeps it
+// from being hoisted out of the loop, and the loads behind it with it, is that its result depends on `when`.)
+RT_DEV const SmallArgs &small_args_again(int when) {
+    const SmallArgs __attribute__((address_space(4))) *p = (const SmallArgs __attribute__((address_space(4))) *)__builtin_amdgcn_kernarg_segment_ptr();
+    asm("" : "+s"(p) : "s"(when));
+    return *(const SmallArgs *)p;
+}
 template <int INTEGRATOR, bool LENS, bool PROBE, bool FUSED>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RT_SMALL_WAVES))) k_pathtrace_small(SmallScene ss, SceneT<float> sc, CameraT<float> cam, RenderParams P,
-                                                          float4 *__restrict__ accum, unsigned long long *__restrict__ counters,
-                                                          const int *__restrict__ tile_perm, int *__restrict__ tile_cost,
-                                                          float4 *__restrict__ partial, int log2_chunks) {
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RT_SMALL_WAVES))) k_pathtrace_small(SmallArgs a) {
+    const SmallScene &ss = a.ss; const SceneT<float> &sc = a.sc; const RenderParams &P = a.P; const int log2_chunks = a.log2_chunks;
     __shared__ SmallShade lds_shade[RTC_SMALL_MAX_LEAVES];
     {   // 48 B x n_leaves, copied dword by dword
         const uint32_t *src = (const uint32_t *)ss.shade;
@@ -313,7 +279,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RT_SMA
     if (item >= (P.n_tiles << log2_chunks)) return;              // wave-uniform
     int tile = item >> log2_chunks;
     const int chunk = item & ((1 << log2_chunks) - 1);
-    if (!PROBE && tile_perm) tile = tile_perm[tile];   // heaviest tiles first (launch_pathtrace_small)
+    if (!PROBE && a.tile_perm) tile = a.tile_perm[tile];   // heaviest tiles first (launch_pathtrace_small)
     const int spp_all = P.s_end - P.s_begin, q = spp_all >> log2_chunks, r = spp_all & ((1 << log2_chunks) - 1);
     const int s_lo = P.s_begin + chunk * q + (chunk < r ? chunk : r), s_hi = s_lo + q + (chunk < r ? 1 : 0);
     // Lanes are not pixels.  The 64 * S paths of the work item (64 pixels x S samples) are numbered q = sample * 64 + pixel
@@ -329,7 +295,6 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RT_SMA
     tile_sum[lane] = 0.0f; tile_sum[64 + lane] = 0.0f; tile_sum[128 + lane] = 0.0f;
     const int tx0 = (tile % P.tiles_x) * 8, ty0 = (tile / P.tiles_x) * 8;
     const int S = s_hi - s_lo, n_paths = 64 * S;
-    const float inv_w = 1.0f / (float)(P.width - 1), inv_h = 1.0f / (float)(P.height - 1);
     const f3 bg = f3mk(sc.background[0], sc.background[1], sc.background[2]);
 
     f3 T = f3mk(1, 1, 1), ro = f3mk(0, 0, 0), rd = f3mk(0, 0, 1);
@@ -357,14 +322,20 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RT_SMA
         int pix; uint32_t smp; locate(q, pix, smp);
         const int px = tx0 + (pix & 7), py = ty0 + (pix >> 3);
         const Rng4 c = rng_block((uint32_t)(py * P.width + px), smp, RT_TAG_CAMERA, P.seed_lo, P.seed_hi);
-        const float u = ((float)px + c.x) * inv_w, v = ((float)py + c.y) * inv_h;
-        float dx = 0.0f, dy = 0.0f;
-        if (LENS) { const float rr = __builtin_amdgcn_sqrtf(c.z); dx = rr * cos2pi(c.w); dy = rr * sin2pi(c.w); }
-#if RT_EXP == 8   // cost probe: the camera's Philox block twice
-        { const Rng4 c2 = rng_block((uint32_t)(py * P.width + px), smp + 77u, RT_TAG_CAMERA, P.seed_lo, P.seed_hi); if (c2.x > 2.0f) dx = c2.y; }
-#endif
-        const RayT<float> r = camera_ray<float>(cam, u, v, dx, dy, 0.0f);   // no leaf moves: the ray time is never read
-        o = r.o; d = (px < P.width && py < P.height) ? normalize(r.d) : f3mk(0, 0, 0);   // unit directions throughout the bounce loop
+        const SmallArgs &t = small_args_again(q_next);                            // the camera's constants: read here, not held across the loop
+        f3 dir;
+        if (LENS) {
+            const float u = ((float)px + c.x) / (float)(t.P.width - 1), v = ((float)py + c.y) / (float)(t.P.height - 1);
+            const float rr = __builtin_amdgcn_sqrtf(c.z);
+            const RayT<float> r = camera_ray<float>(t.cam, u, v, rr * cos2pi(c.w), rr * sin2pi(c.w), 0.0f);   // no leaf moves: the ray time is never read
+            o = r.o; dir = r.d;
+        } else {   // pinhole: direction = base + hs (px + jx) + vs (py + jy), folded on the host (rtc_api.cpp; camera.c:46-53, main.c:150-151)
+            const float fx = (float)px + c.x, fy = (float)py + c.y;
+            dir = f3mk(__builtin_fmaf(t.P.cam_vs[0], fy, __builtin_fmaf(t.P.cam_hs[0], fx, t.P.cam_base[0])), __builtin_fmaf(t.P.cam_vs[1], fy, __builtin_fmaf(t.P.cam_hs[1], fx, t.P.cam_base[1])),
+                       __builtin_fmaf(t.P.cam_vs[2], fy, __builtin_fmaf(t.P.cam_hs[2], fx, t.P.cam_base[2])));
+            o = f3mk(0, 0, 0);                                              // (not buffered: the bounce loop takes the camera's origin)
+        }
+        d = (px < t.P.width && py < t.P.height) ? normalize(dir) : f3mk(0, 0, 0);   // unit directions throughout the bounce loop
     };
     // the next paths go to the lanes of `want`, in lane order
     auto hand_out = [&](bool want, int &q) -> bool {
@@ -386,7 +357,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RT_SMA
             locate(b0q, cur_pix, s_cur); --n_buf;
             pixel = (uint32_t)((ty0 + (cur_pix >> 3)) * P.width + tx0 + (cur_pix & 7));
             rd = b0d; b0d = b1d; b0q = b1q;
-            if (LENS) { ro = b0o; b0o = b1o; } else ro = f3mk(cam.origin[0], cam.origin[1], cam.origin[2]);
+            if (LENS) { ro = b0o; b0o = b1o; } else ro = f3mk(a.cam.origin[0], a.cam.origin[1], a.cam.origin[2]);
             T = f3mk(1, 1, 1);
             depth = 0; src = -1; pend = 0.0f;
             alive = rd.x != 0.0f || rd.y != 0.0f || rd.z != 0.0f;          // a pixel outside the image: nothing to trace
@@ -398,9 +369,6 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RT_SMA
         if (alive) {
             float pdf_ray;
             h = small_closest_hit<fused>(ss, ro, rd, 0.001f, src, pdf_ray);  // ray.c:56
-#if RT_EXP == 1   // cost probe: intersection twice (second call perturbed so it is not CSE'd)
-            { float p2; const SmallHit h2 = small_closest_hit<false>(ss, ro, rd, 0.001f + 1e-9f * (float)iters, src, p2); if (h2.t < h.t) h = h2; }
-#endif
             ++nrays;
             if (fused && pend > 0.0f) {                               // complete the previous bounce: T *= pdf_cos / pdf_val (ray.c:80-83)
                 // (pend > 0 and a cosine weight > 0 make pdf_val > 0; a pdf_val of 0 or NaN -- cosine weight 0, a ray from inside a light
@@ -428,9 +396,6 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RT_SMA
                 if (sh.meta & RTC_SF_FLIP) front = !front;                  // flip_face_hit, hittable.c:587-591
                 const f3 col = f3mk(sh.rgb[0], sh.rgb[1], sh.rgb[2]);
                 Rng4 xi = rng_block(pixel, s_cur, (uint32_t)depth, P.seed_lo, P.seed_hi);
-#if RT_EXP == 2   // cost probe: bounce Philox twice
-                { const Rng4 x2 = rng_block(pixel, s_cur, (uint32_t)depth + 77u, P.seed_lo, P.seed_hi); if (x2.x > 2.0f) xi = x2; }
-#endif
                 done = false;
                 f3 nd = rd;
                 if (mtype == RTC_MAT_LIGHT) {                               // material.c:229-235 (03: front face only, F15); no scatter
@@ -443,9 +408,6 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RT_SMA
                     T = T * col;
                 } else if (mtype == RTC_MAT_DIELECTRIC) {                   // material.c:144-162
                     nd = small_dielectric_dir(sh.param, sh.pad[0], sh.pad[1], rd, n, front, xi.x);
-#if RT_EXP == 7   // cost probe: the glass arm's direction twice
-                    { const f3 n2 = small_dielectric_dir(sh.param, sh.pad[0], sh.pad[1], rd + f3mk(1e-9f * (float)iters, 0, 0), n, front, xi.x); if (n2.x > 3.0e38f) nd = n2; }
-#endif
                 } else if (mtype == RTC_MAT_ISOTROPIC) {
                     done = true;                                            // only reachable through a medium; none in a small scene
                 } else if (INTEGRATOR != 0) {                               // 02 material.c:120-128: normal + random unit vector
@@ -463,16 +425,6 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RT_SMA
                         nd = n + uniform_sphere(xi.z, xi.w);
                         if (len2(nd) < 1e-12f) nd = n;
                     }
-#if RT_EXP == 6   // cost probe: direction sampling (light list or cosine law) twice
-                    {
-                        f3 n2;
-                        if (sc.n_lights > 0 && xi.x < w) {
-                            int pick = (int)((float)sc.n_lights * xi.y); pick = pick < sc.n_lights ? pick : sc.n_lights - 1;
-                            n2 = small_light_sample(sc, pick, p + f3mk(1e-9f * (float)iters, 0, 0), xi.w, xi.z);
-                        } else n2 = n + uniform_sphere(xi.w, xi.z);
-                        if (n2.x > 3.0e38f) nd = n2;
-                    }
-#endif
                     nd = nd * __builtin_amdgcn_rsqf(len2(nd));              // unit from here on: the pdfs and the next bounce's tests drop |v|
                     const float pdf_cos = lambert_pdf(n, nd);                         // pdf.c:100-103 == material.c:205-208
                     if (fused) {                                            // the light-list pdf of nd arrives with the next intersection
@@ -480,12 +432,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RT_SMA
                         else { T = T * col; pend = pdf_cos; }
                     } else {
                     const float pdf_light = sc.n_lights > 0 ? small_light_pdf_sum(sc, p, nd) : 0.0f;   // x 1 / n_lights below
-#if RT_EXP == 5   // cost probe: the light-list pdf twice
-                    const float pdf_light2 = sc.n_lights > 0 ? small_light_pdf_sum(sc, p + f3mk(1e-9f * (float)iters, 0, 0), nd) : 0.0f;
-                    const float pdf_val = P.light_weight_each * (pdf_light2 > 3.0e38f ? pdf_light2 : pdf_light) + P.cosine_weight * pdf_cos;
-#else
                     const float pdf_val = P.light_weight_each * pdf_light + P.cosine_weight * pdf_cos;  // pdf.c:119-121
-#endif
                     // scattering pdf 0: the reference recurses and multiplies by 0; pdf_val 0: 0/0 (scrubbed) -- nothing more arrives
                     if (!(pdf_cos > 0.0f) || !(pdf_val > 0.0f)) done = true;
                     else T = T * (col * (pdf_cos * __builtin_amdgcn_rcpf(pdf_val)));
@@ -505,18 +452,19 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RT_SMA
     unsigned total = nrays;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) total += __shfl_xor(total, off, 64);
-    if (PROBE) { if (lane == 0) tile_cost[tile] = (int)total; return; }   // cost probe: rays of this tile, nothing else is written
+    const SmallArgs &e = small_args_again(q_next);
+    if (PROBE) { if (lane == 0) e.tile_cost[tile] = (int)total; return; }   // cost probe: rays of this tile, nothing else is written
     const int px = tx0 + (lane & 7), py = ty0 + (lane >> 3);
-    if (px < P.width && py < P.height) {                     // lane l writes pixel l of the tile
-        const size_t pix_id = (size_t)py * P.width + px;
+    if (px < e.P.width && py < e.P.height) {                 // lane l writes pixel l of the tile
+        const size_t pix_id = (size_t)py * e.P.width + px;
         const f3 sum = f3mk(tile_sum[lane], tile_sum[64 + lane], tile_sum[128 + lane]);
-        if (log2_chunks == 0) {                                            // the only wave of this pixel: straight into the accumulator
-            float4 a = accum[pix_id];
-            a.x += sum.x; a.y += sum.y; a.z += sum.z; a.w += (float)(s_hi - s_lo);
-            accum[pix_id] = a;
-        } else partial[(size_t)chunk * ((size_t)P.width * P.height) + pix_id] = make_float4(sum.x, sum.y, sum.z, (float)(s_hi - s_lo));
+        if (e.log2_chunks == 0) {                                          // the only wave of this pixel: straight into the accumulator
+            float4 acc = e.accum[pix_id];
+            acc.x += sum.x; acc.y += sum.y; acc.z += sum.z; acc.w += (float)(s_hi - s_lo);
+            e.accum[pix_id] = acc;
+        } else e.partial[(size_t)chunk * ((size_t)e.P.width * e.P.height) + pix_id] = make_float4(sum.x, sum.y, sum.z, (float)(s_hi - s_lo));
     }
-    if (lane == 0) { atomicAdd(counters, (unsigned long long)total); atomicAdd(counters + 1, (unsigned long long)iters); }
+    if (lane == 0) { atomicAdd(e.counters, (unsigned long long)total); atomicAdd(e.counters + 1, (unsigned long long)iters); }
 }
 
 // accum += the partial sums of a pixel's chunks, in chunk order: the result does not depend on which wave finished first
@@ -574,11 +522,12 @@ template <bool PROBE>
 static void launch_small(const SmallScene &ss, const SceneT<float> &sc, const CameraT<float> &cam, const RenderParams &p, float4 *accum,
                          unsigned long long *counters, const int *perm, int *cost, float4 *partial, int log2_chunks, hipStream_t stream) {
     const unsigned blocks = (unsigned)((((long long)p.n_tiles << log2_chunks) + 3) / 4);
-#define RT_SMALL_LAUNCH(I, L) hipLaunchKernelGGL((k_pathtrace_small<I, L, PROBE, false>), dim3(blocks), dim3(256), 0, stream, ss, sc, cam, p, accum, counters, perm, cost, partial, log2_chunks)
+    const SmallArgs args{ss, sc, cam, p, accum, counters, perm, cost, partial, log2_chunks};
+#define RT_SMALL_LAUNCH(I, L) hipLaunchKernelGGL((k_pathtrace_small<I, L, PROBE, false>), dim3(blocks), dim3(256), 0, stream, args)
     const bool lens = cam.lens_radius > 0.0f;
     if (p.integrator == 0 && ss.fused_lights) {
-        if (lens) hipLaunchKernelGGL((k_pathtrace_small<0, true, PROBE, true>), dim3(blocks), dim3(256), 0, stream, ss, sc, cam, p, accum, counters, perm, cost, partial, log2_chunks);
-        else hipLaunchKernelGGL((k_pathtrace_small<0, false, PROBE, true>), dim3(blocks), dim3(256), 0, stream, ss, sc, cam, p, accum, counters, perm, cost, partial, log2_chunks);
+        if (lens) hipLaunchKernelGGL((k_pathtrace_small<0, true, PROBE, true>), dim3(blocks), dim3(256), 0, stream, args);
+        else hipLaunchKernelGGL((k_pathtrace_small<0, false, PROBE, true>), dim3(blocks), dim3(256), 0, stream, args);
     }
     else if (p.integrator == 0) { if (lens) RT_SMALL_LAUNCH(0, true); else RT_SMALL_LAUNCH(0, false); }
     else if (p.integrator == 1) { if (lens) RT_SMALL_LAUNCH(1, true); else RT_SMALL_LAUNCH(1, false); }

@@ -145,9 +145,12 @@ __device__ __forceinline__ bool wf_shade_entry(const SceneT<float> &sc, const Ca
 // the kernels spilled up to 86 SGPRs to vector lanes.  wf_args_again() hands out the kernel-argument segment through a pointer the
 // compiler cannot see through, so what is read through it is (re)loaded by s_load where the tail stands -- behind the loop.
 struct WfArgs { SceneT<float> sc; CameraT<float> cam; RenderParams P; WfBuffers B; };
-__device__ __forceinline__ const WfArgs &wf_args_again() {
+// (`when` = a wave-uniform value that differs from use to use.  The asm statement is not volatile -- a volatile one counts as a write
+// to memory, and hipcc then stops using scalar loads for uniform reads behind it -- so what keeps it, and the loads behind it, from
+// being hoisted to the top of the kernel is that its result depends on `when`.)
+__device__ __forceinline__ const WfArgs &wf_args_again(unsigned when) {
     const WfArgs __attribute__((address_space(4))) *p = (const WfArgs __attribute__((address_space(4))) *)__builtin_amdgcn_kernarg_segment_ptr();
-    asm volatile("" : "+s"(p));
+    asm("" : "+s"(p) : "s"(when));
     return *(const WfArgs *)p;
 }
 // The tail of both extend kernels: a hit whose shading record is complete is shaded where it was found -- the ray state is still in
@@ -237,7 +240,7 @@ __global__ void __launch_bounds__(kWfExtendBlock) __attribute__((amdgpu_waves_pe
         }
         LdsStack stack(lds_stack + threadIdx.x, kWfExtendBlock, sc.bvh_stack);
         const HitS h = bvh_closest_hit<KINDS>(sc, r, 0.001f, Mth<float>::inf(), stack, medium, src_slot);   // ray.c:56
-        const WfArgs &t = wf_args_again();
+        const WfArgs &t = wf_args_again(n_list);
         died = wf_extend_tail(t.sc, t.cam, t.P, t.B, slot, px, py, o, d, tm, h, key);
         if (died) t.B.active[cur][i] = -1;                           // stays in the list as a hole until the next compaction
     }
@@ -301,7 +304,7 @@ __global__ void __launch_bounds__(kWfLdsBlock) __attribute__((amdgpu_waves_per_e
             NoMedium32 medium;
             LdsStack16 stack(stacks + threadIdx.x, kWfLdsBlock, sc.bvh_stack);
             const HitS h = bvh_closest_hit_tab<KINDS>(sc, node_tab, leaf_tab, r, 0.001f, Mth<float>::inf(), stack, medium, src_slot);   // ray.c:56
-            const WfArgs &t = wf_args_again();
+            const WfArgs &t = wf_args_again(chunk);
             int px, py, layer; slot_pixel(t.P, t.B, slot, px, py, layer);
             died = wf_extend_tail(t.sc, t.cam, t.P, t.B, slot, px, py, o, d, tm, h, key);
             if (died) t.B.active[cur][i] = -1;

@@ -5,6 +5,8 @@
 
 #include <algorithm>
 #include <chrono>
+#include <cmath>
+#include <limits>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -21,12 +23,16 @@
 #include "host/flatten.h"
 #include "host/scene_io.h"
 #include "rtc.h"
+#include "rtc_test.h"
 
 namespace {
 
 thread_local std::string g_error;
 thread_local const char *g_error_literal = nullptr;   // set by fail_literal: an error path that must not touch the heap
+// every error goes through fail / fail_scene / fail_literal: the first two clear the literal, so that a refusal of the allocation-free
+// entry point never outlives a later error on the same thread
 int fail(int code, const std::string &msg) { g_error = msg; g_error_literal = nullptr; return code; }
+
 int fail_literal(int code, const char *msg) { g_error_literal = msg; return code; }
 #define HIP_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return fail(RTC_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_)); } while (0)
 
@@ -69,7 +75,21 @@ template <typename R> hipError_t upload_tables(const FlatScene &fs, DeviceTables
     UP(perlin_vec, pvec); UP(perlin_perm, fs.perlin_perm); UP(images, fs.images); UP(image_data, fs.image_data); UP(leaf_prims, fs.leaf_prims);
     if (with_ref_steps) { UP(ref_steps, fs.ref_steps); UP(ref_boxes, fs.ref_boxes); }
     else {
-        UP(nodes, fs.nodes);
+        {   // lo / hi -> centre / half-extent (BvhNodeCH), rounded so that [c - h, c + h] still encloses the builder's padded box
+            std::vector<BvhNodeCH> ch(fs.nodes.size());
+            for (size_t i = 0; i < fs.nodes.size(); i++) {
+                const BvhNode &n = fs.nodes[i]; BvhNodeCH &o = ch[i];
+                o.child0 = n.child0; o.count0 = n.count0; o.child1 = n.child1; o.count1 = n.count1;
+                auto conv1 = [](float lo, float hi, float &c, float &h) {
+                    if (!(lo <= hi)) { c = 0.0f; h = -1.0f; return; }                      // the empty child of a one-leaf tree: never entered
+                    c = (float)(0.5 * ((double)lo + (double)hi));
+                    const double need = std::max((double)hi - (double)c, (double)c - (double)lo);
+                    h = (float)need; if ((double)h < need) h = std::nextafter(h, std::numeric_limits<float>::infinity());
+                };
+                for (int a = 0; a < 3; a++) { conv1(n.lo0[a], n.hi0[a], o.c0[a], o.h0[a]); conv1(n.lo1[a], n.hi1[a], o.c1[a], o.h1[a]); }
+            }
+            UP(nodes, ch);
+        }
         UP(bleaves, fs.bleaves); UP(leaf_shade, fs.leaf_shade);
     }
 #undef UP
@@ -82,7 +102,7 @@ template <typename R> hipError_t upload_tables(const FlatScene &fs, DeviceTables
     v.lights = (const LightT<R> *)dt.lights.p; v.n_lights = (int)fs.lights.size();
     v.perlin_vec = (const R *)dt.perlin_vec.p; v.perlin_perm = (const int *)dt.perlin_perm.p;
     v.images = (const ImageDesc *)dt.images.p; v.image_data = (const unsigned char *)dt.image_data.p;
-    v.nodes = (const BvhNode *)dt.nodes.p; v.leaf_prims = (const int *)dt.leaf_prims.p; v.n_nodes = (int)fs.nodes.size();
+    v.nodes = (const BvhNodeCH *)dt.nodes.p; v.leaf_prims = (const int *)dt.leaf_prims.p; v.n_nodes = (int)fs.nodes.size();
     v.bleaves = (const BLeaf *)dt.bleaves.p; v.leaf_shade = (const SmallShade *)dt.leaf_shade.p;
     v.ref_steps = (const RefStep *)dt.ref_steps.p; v.ref_boxes = (const double *)dt.ref_boxes.p;
     v.n_ref_steps = with_ref_steps ? (int)fs.ref_steps.size() : 0;
@@ -169,6 +189,8 @@ struct rtc_scene {
     ~rtc_scene() { if (wf_done) (void)hipEventDestroy(wf_done); if (wf_fork) (void)hipEventDestroy(wf_fork); for (int k = 0; k < 4; k++) { if (wf_part_done[k]) (void)hipEventDestroy(wf_part_done[k]); if (wf_stream[k]) (void)hipStreamDestroy(wf_stream[k]); } for (auto &kv : streams) { if (kv.second.ev0) (void)hipEventDestroy(kv.second.ev0); if (kv.second.ev1) (void)hipEventDestroy(kv.second.ev1); } }
 };
 
+static rtc_scene *fail_scene(rtc_scene *doomed, const std::string &msg) { g_error = msg; g_error_literal = nullptr; delete doomed; return nullptr; }
+
 extern "C" {
 
 const char *rtc_last_error(void) { return g_error_literal ? g_error_literal : g_error.c_str(); }
@@ -194,7 +216,7 @@ const char *rtc_device_name(void) {
 
 // device tables of a flattened scene on the current device (rtc_scene_build and rtc_scene_load)
 static rtc_scene *upload_scene(rtc_scene *s, const char *who) {
-    if (hipGetDevice(&s->device) != hipSuccess) { g_error = std::string(who) + ": no current HIP device"; delete s; return nullptr; }
+    if (hipGetDevice(&s->device) != hipSuccess) return fail_scene(s, std::string(who) + ": no current HIP device");
     hipError_t e = upload_tables<float>(s->flat, s->f32, false);
     std::vector<unsigned char> zero(4 * (wf_stats_bytes() + 64), 0);   // per part of a wavefront render: striped statistics, 16 control words (kernels.h WF_*)
     if (e == hipSuccess) e = s->ray_counter.upload(zero.data(), zero.size());
@@ -215,7 +237,11 @@ static rtc_scene *upload_scene(rtc_scene *s, const char *who) {
         m.n_xforms = (int)fs.small_xforms.size(); m.n_leaves = (int)fs.small_shade.size(); m.any_fuzz = fs.small_any_fuzz;
         m.fused_lights = fs.small_fused;
     }
-    if (e != hipSuccess) { g_error = std::string(who) + ": upload failed: " + hipGetErrorString(e); delete s; return nullptr; }
+    if (e != hipSuccess) return fail_scene(s, std::string(who) + ": upload failed: " + hipGetErrorString(e));
+    // the allocation-free entry point's scratch: resolve its address on THIS device now (hipGetSymbolAddress may load the code object,
+    // which allocates and is not legal during stream capture) -- a scene upload on a device is that entry point's warm-up there
+    void *scratch_ptr = nullptr;
+    if (noalloc_scratch(&scratch_ptr) != RTC_OK) { const std::string why = rtc_last_error(); return fail_scene(s, std::string(who) + ": " + why); }
     return s;
 }
 
@@ -226,12 +252,12 @@ static int bvh_threshold() { const char *e = std::getenv("RTC_BVH_THRESHOLD"); r
 rtc_scene *rtc_scene_build(const hittable_list *world, const hittable_list *lights, const color *background, double time0, double time1) {
     rtc_scene *s = new rtc_scene();
     // brute force up to 64 leaves: the uniform loop runs out of SGPR-fed scalar loads; above that the linear BVH wins
-    if (!flatten_scene(world, lights, background, time0, time1, bvh_threshold(), s->flat)) { g_error = "flatten: " + s->flat.error; delete s; return nullptr; }
+    if (!flatten_scene(world, lights, background, time0, time1, bvh_threshold(), s->flat)) return fail_scene(s, "flatten: " + s->flat.error);
     return upload_scene(s, "rtc_scene_build");
 }
 rtc_scene *rtc_scene_flatten_only(const hittable_list *world, const hittable_list *lights, const color *background, double time0, double time1) {
     rtc_scene *s = new rtc_scene();
-    if (!flatten_scene(world, lights, background, time0, time1, bvh_threshold(), s->flat)) { g_error = "flatten: " + s->flat.error; delete s; return nullptr; }
+    if (!flatten_scene(world, lights, background, time0, time1, bvh_threshold(), s->flat)) return fail_scene(s, "flatten: " + s->flat.error);
     return s;   // device == -1: every compute entry point refuses this handle
 }
 int rtc_scene_save(const rtc_scene *scene, const char *path) {
@@ -241,17 +267,18 @@ int rtc_scene_save(const rtc_scene *scene, const char *path) {
     return RTC_OK;
 }
 rtc_scene *rtc_scene_load_host(const char *path) {
-    if (!path) { g_error = "rtc_scene_load: null path"; return nullptr; }
+    if (!path) return fail_scene(nullptr, "rtc_scene_load: null path");
     rtc_scene *s = new rtc_scene();
     std::string err;
-    if (!load_flat_scene(path, s->flat, err)) { g_error = "rtc_scene_load: " + err; delete s; return nullptr; }
+    if (!load_flat_scene(path, s->flat, err)) return fail_scene(s, "rtc_scene_load: " + err);
     return s;   // device == -1, like rtc_scene_flatten_only
 }
 rtc_scene *rtc_scene_load(const char *path) {
     rtc_scene *s = rtc_scene_load_host(path);
     return s ? upload_scene(s, "rtc_scene_load") : nullptr;
 }
-void rtc_scene_free(rtc_scene *scene) { delete scene; }
+static void multi_forget(const rtc_scene *s);
+void rtc_scene_free(rtc_scene *scene) { if (scene) multi_forget(scene); delete scene; }
 int rtc_scene_num_prims(const rtc_scene *scene) { return scene ? (int)scene->flat.prims.size() : RTC_ERR_ARG; }
 
 int rtc_scene_dump_leaves(const rtc_scene *scene, double *out16, int cap) {
@@ -427,7 +454,10 @@ static int render_wavefront(rtc_scene *s, const CameraT<float> &camf, const Rend
     const int spp_all = p_all.s_end - p_all.s_begin;
     if (spp_all <= 0) return RTC_OK;
     const long long per_layer = (long long)p_all.n_tiles * 64;
-    int n_parts = spp_all >= 48 ? 3 : (spp_all >= 16 ? 2 : 1);
+    // parts of at least ~5 M path slots each: smaller ones lose more to their launches than the overlap gains (final 512^2 x 256 spp, 8.4 M slots:
+    // one part 33.9 ms, three 37.4; 1024^2, 32 M slots: 116 against 94)
+    const long long slots_wanted = std::min<long long>((long long)((spp_all + 7) / 8) * per_layer, 32ll << 20);
+    int n_parts = (int)std::max<long long>(1, std::min<long long>(3, slots_wanted / (5ll << 20)));
     if (const char *e = std::getenv("RTC_WF_PARTS")) { const int v = std::atoi(e); if (v >= 1 && v <= RTC_WF_MAX_PARTS) n_parts = v; }   // A/B knob
     if (n_parts > spp_all) n_parts = spp_all;
     // Slots per pixel ("layers").  A slot walks through its samples one after the other, so a render lasts as many bounces
@@ -767,11 +797,11 @@ color ray_color(ray *r, color *background, hittable_list *world, hittable_list *
 
 // A copy of a scene's tables on another device (the flattening is not repeated).
 rtc_scene *rtc_scene_clone_to_device(const rtc_scene *scene, int device) {
-    if (!scene) { g_error = "rtc_scene_clone_to_device: null scene"; g_error_literal = nullptr; return nullptr; }
+    if (!scene) return fail_scene(nullptr, "rtc_scene_clone_to_device: null scene");
     int n = 0, prev = -1;
-    if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) { g_error = "rtc_scene_clone_to_device: no such HIP device"; g_error_literal = nullptr; return nullptr; }
+    if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) return fail_scene(nullptr, "rtc_scene_clone_to_device: no such HIP device");
     (void)hipGetDevice(&prev);
-    if (hipSetDevice(device) != hipSuccess) { g_error = "rtc_scene_clone_to_device: hipSetDevice failed"; g_error_literal = nullptr; return nullptr; }
+    if (hipSetDevice(device) != hipSuccess) return fail_scene(nullptr, "rtc_scene_clone_to_device: hipSetDevice failed");
     rtc_scene *s = new rtc_scene();
     s->flat = scene->flat;
     s = upload_scene(s, "rtc_scene_clone_to_device");
@@ -779,8 +809,29 @@ rtc_scene *rtc_scene_clone_to_device(const rtc_scene *scene, int device) {
     return s;
 }
 
-// BASELINE config 4 from a C host: one host thread per scene handle (= per device), disjoint sample shards, the accumulators
-// brought to the first handle's device by peer copies and added there in handle order, one download.
+// BASELINE config 4 from a C host: disjoint sample shards, one per scene handle (= per device), the accumulators brought to the first
+// handle's device by peer copies and added there in handle order, one download.  Every entry point below only enqueues (the wavefront
+// path too), so ONE host thread feeds all devices: per handle a stream, an accumulator and -- on the root -- a staging buffer are kept on
+// the handle between calls; the N - 1 peer copies run side by side on streams of their own as their renders finish; one kernel adds
+// them in handle order; the call synchronises once, at the end.
+struct MultiState {                                     // owned by a handle, lives on its device
+    hipStream_t stream = nullptr; hipEvent_t rendered = nullptr, staged = nullptr;
+    DevBuf acc; DevBuf stage;                           // stage: on the ROOT device, for this handle's accumulator
+    int stage_device = -1;
+    ~MultiState() { if (stream) (void)hipStreamDestroy(stream); if (rendered) (void)hipEventDestroy(rendered); if (staged) (void)hipEventDestroy(staged); }
+};
+static std::map<const rtc_scene *, MultiState> g_multi;
+static std::mutex g_multi_mu;
+static void multi_forget(const rtc_scene *s) {         // rtc_scene_free: the handle's buffers go with it
+    std::lock_guard<std::mutex> lk(g_multi_mu);
+    auto it = g_multi.find(s);
+    if (it == g_multi.end()) return;
+    int prev = -1; (void)hipGetDevice(&prev);
+    if (s->device >= 0) (void)hipSetDevice(s->device);
+    { MultiState &m = it->second; if (m.stage.p && m.stage_device >= 0) { (void)hipSetDevice(m.stage_device); (void)hipFree(m.stage.p); m.stage.p = nullptr; (void)hipSetDevice(s->device); } }
+    g_multi.erase(it);
+    if (prev >= 0) (void)hipSetDevice(prev);
+}
 int rtc_render_multi(const rtc_scene *const *scenes, int n_scenes, const camera *cam, const rtc_settings *st, float *accum_host) {
     if (!scenes || n_scenes < 1 || !cam || !accum_host) return fail(RTC_ERR_ARG, "rtc_render_multi: null argument");
     if (n_scenes > 64) return fail(RTC_ERR_ARG, "rtc_render_multi: at most 64 scene handles");
@@ -789,52 +840,64 @@ int rtc_render_multi(const rtc_scene *const *scenes, int n_scenes, const camera 
     for (int i = 0; i < n_scenes; i++) for (int j = 0; j < i; j++) if (scenes[i] == scenes[j]) return fail(RTC_ERR_ARG, "rtc_render_multi: the same scene handle twice (clone it: rtc_scene_clone_to_device)");
     const size_t n_pix = (size_t)st->width * st->height, bytes = n_pix * 4 * sizeof(float);
     const int spp = st->sample_end - st->sample_begin, q = spp / n_scenes, r = spp % n_scenes;
-    int prev = -1; (void)hipGetDevice(&prev);
-    std::vector<void *> acc((size_t)n_scenes, nullptr);
-    std::vector<int> status((size_t)n_scenes, RTC_OK);
-    std::vector<std::string> message((size_t)n_scenes);
-    std::vector<std::thread> threads;
-    for (int i = 0; i < n_scenes; i++)
-        threads.emplace_back([&, i]() {
-            // shard i: contiguous, disjoint, exhaustive -- earlier handles take the remainder (raytracer_amd/dist.py shard_samples)
-            rtc_settings mine = *st;
-            mine.sample_begin = st->sample_begin + i * q + std::min(i, r);
-            mine.sample_end = mine.sample_begin + q + (i < r ? 1 : 0);
-            auto bad = [&](const char *what) { status[(size_t)i] = RTC_ERR_DEVICE; message[(size_t)i] = std::string("rtc_render_multi, handle ") + std::to_string(i) + ": " + what; };
-            if (hipSetDevice(scenes[i]->device) != hipSuccess) return bad("hipSetDevice failed");
-            if (hipMalloc(&acc[(size_t)i], bytes) != hipSuccess) { acc[(size_t)i] = nullptr; status[(size_t)i] = RTC_ERR_NOMEM; message[(size_t)i] = "rtc_render_multi: accumulator does not fit in device memory"; return; }
-            if (hipMemset(acc[(size_t)i], 0, bytes) != hipSuccess) return bad("hipMemset failed");
-            if (mine.sample_end > mine.sample_begin) {
-                const int rc_i = rtc_render_device(scenes[i], cam, &mine, (float *)acc[(size_t)i], nullptr);
-                if (rc_i != RTC_OK) { status[(size_t)i] = rc_i; message[(size_t)i] = rtc_last_error(); return; }
-            }
-            if (hipDeviceSynchronize() != hipSuccess) return bad("the render failed on the device");
-        });
-    for (auto &t : threads) t.join();
-    int first_bad = -1;
-    for (int i = 0; i < n_scenes && first_bad < 0; i++) if (status[(size_t)i] != RTC_OK) first_bad = i;
-    hipError_t e = hipSuccess;
     const int root = scenes[0]->device;
-    void *stage = nullptr;
-    if (first_bad < 0) {
-        e = hipSetDevice(root);
-        if (e == hipSuccess && n_scenes > 1) e = hipMalloc(&stage, bytes);
-        for (int i = 1; i < n_scenes && e == hipSuccess; i++) {          // fixed order: the sum does not depend on which device finished first
-            e = hipMemcpyPeer(stage, root, acc[(size_t)i], scenes[i]->device, bytes);   // xGMI when peers can see each other, staged through the host otherwise
-            if (e == hipSuccess) e = launch_accum_add((float4 *)acc[0], (const float4 *)stage, n_pix, nullptr);
-            if (e == hipSuccess) e = hipDeviceSynchronize();
+    int prev = -1; (void)hipGetDevice(&prev);
+    std::lock_guard<std::mutex> lk(g_multi_mu);
+    struct Restore { int d; ~Restore() { if (d >= 0) (void)hipSetDevice(d); } } restore{prev};
+    auto dev_fail = [&](int i, const char *what, hipError_t e) { return fail(RTC_ERR_DEVICE, std::string("rtc_render_multi, handle ") + std::to_string(i) + ": " + what + ": " + hipGetErrorString(e)); };
+    std::vector<MultiState *> ms((size_t)n_scenes);
+    hipError_t e;
+    // set-up (first call, or another image size): streams, events, accumulators, staging buffers on the root
+    for (int i = 0; i < n_scenes; i++) {
+        MultiState &m = g_multi[scenes[i]]; ms[(size_t)i] = &m;
+        if ((e = hipSetDevice(scenes[i]->device)) != hipSuccess) return dev_fail(i, "hipSetDevice", e);
+        if (!m.stream) {
+            if ((e = hipStreamCreateWithFlags(&m.stream, hipStreamNonBlocking)) != hipSuccess) return dev_fail(i, "hipStreamCreate", e);
+            if ((e = hipEventCreateWithFlags(&m.rendered, hipEventDisableTiming)) != hipSuccess || (e = hipEventCreateWithFlags(&m.staged, hipEventDisableTiming)) != hipSuccess) return dev_fail(i, "hipEventCreate", e);
         }
-        if (e == hipSuccess) {
-            std::vector<float> sum(n_pix * 4);
-            e = hipMemcpy(sum.data(), acc[0], bytes, hipMemcpyDeviceToHost);
-            if (e == hipSuccess) for (size_t k = 0; k < sum.size(); k++) accum_host[k] += sum[k];   // the call ADDS, like rtc_render
+        if (m.acc.bytes != bytes) {
+            if (m.acc.p) { (void)hipStreamSynchronize(m.stream); (void)hipFree(m.acc.p); m.acc.p = nullptr; m.acc.bytes = 0; }
+            if (hipMalloc(&m.acc.p, bytes) != hipSuccess) { m.acc.p = nullptr; return fail(RTC_ERR_NOMEM, "rtc_render_multi: accumulator does not fit in device memory"); }
+            m.acc.bytes = bytes;
+        }
+        if (i > 0 && (m.stage.bytes != bytes || m.stage_device != root)) {
+            if (m.stage.p) { (void)hipSetDevice(m.stage_device); (void)hipDeviceSynchronize(); (void)hipFree(m.stage.p); m.stage.p = nullptr; m.stage.bytes = 0; }
+            if ((e = hipSetDevice(root)) != hipSuccess) return dev_fail(i, "hipSetDevice(root)", e);
+            if (hipMalloc(&m.stage.p, bytes) != hipSuccess) { m.stage.p = nullptr; return fail(RTC_ERR_NOMEM, "rtc_render_multi: staging buffer does not fit in device memory"); }
+            m.stage.bytes = bytes; m.stage_device = root;
         }
     }
-    for (int i = 0; i < n_scenes; i++) if (acc[(size_t)i]) { (void)hipSetDevice(scenes[i]->device); (void)hipFree(acc[(size_t)i]); }
-    if (stage) { (void)hipSetDevice(root); (void)hipFree(stage); }
-    if (prev >= 0) (void)hipSetDevice(prev);
-    if (first_bad >= 0) return fail(status[(size_t)first_bad], message[(size_t)first_bad]);
-    if (e != hipSuccess) return fail(RTC_ERR_DEVICE, std::string("rtc_render_multi: reduce failed: ") + hipGetErrorString(e));
+    // enqueue: the root starts from the caller's sums (the call ADDS, like rtc_render), the others from zero
+    for (int i = 0; i < n_scenes; i++) {
+        MultiState &m = *ms[(size_t)i];
+        if ((e = hipSetDevice(scenes[i]->device)) != hipSuccess) return dev_fail(i, "hipSetDevice", e);
+        e = i == 0 ? hipMemcpyAsync(m.acc.p, accum_host, bytes, hipMemcpyHostToDevice, m.stream) : hipMemsetAsync(m.acc.p, 0, bytes, m.stream);
+        if (e != hipSuccess) return dev_fail(i, "accumulator set-up", e);
+        // shard i: contiguous, disjoint, exhaustive -- earlier handles take the remainder (raytracer_amd/dist.py shard_samples)
+        rtc_settings mine = *st;
+        mine.sample_begin = st->sample_begin + i * q + std::min(i, r);
+        mine.sample_end = mine.sample_begin + q + (i < r ? 1 : 0);
+        if (mine.sample_end > mine.sample_begin) {
+            const int rc_i = rtc_render_device(scenes[i], cam, &mine, (float *)m.acc.p, m.stream);
+            if (rc_i != RTC_OK) { const std::string why = rtc_last_error(); for (int k = 0; k <= i; k++) { (void)hipSetDevice(scenes[k]->device); (void)hipStreamSynchronize(ms[(size_t)k]->stream); } return fail(rc_i, why); }
+        }
+        if ((e = hipEventRecord(m.rendered, m.stream)) != hipSuccess) return dev_fail(i, "hipEventRecord", e);
+    }
+    // gather on the root: every copy waits for its own render only (xGMI when the peers see each other, through the host otherwise)
+    if ((e = hipSetDevice(root)) != hipSuccess) return dev_fail(0, "hipSetDevice(root)", e);
+    std::vector<const float4 *> staged;
+    for (int i = 1; i < n_scenes; i++) {
+        MultiState &m = *ms[(size_t)i];
+        if ((e = hipSetDevice(scenes[i]->device)) != hipSuccess) return dev_fail(i, "hipSetDevice", e);
+        if ((e = hipMemcpyPeerAsync(m.stage.p, root, m.acc.p, scenes[i]->device, bytes, m.stream)) != hipSuccess) return dev_fail(i, "hipMemcpyPeerAsync", e);
+        if ((e = hipEventRecord(m.staged, m.stream)) != hipSuccess) return dev_fail(i, "hipEventRecord", e);
+        if ((e = hipSetDevice(root)) != hipSuccess) return dev_fail(0, "hipSetDevice(root)", e);
+        if ((e = hipStreamWaitEvent(ms[0]->stream, m.staged, 0)) != hipSuccess) return dev_fail(i, "hipStreamWaitEvent", e);
+        staged.push_back((const float4 *)m.stage.p);
+    }
+    if (!staged.empty() && (e = launch_accum_add((float4 *)ms[0]->acc.p, staged.data(), (int)staged.size(), n_pix, ms[0]->stream)) != hipSuccess) return dev_fail(0, "sum of the shards", e);
+    if ((e = hipMemcpyAsync(accum_host, ms[0]->acc.p, bytes, hipMemcpyDeviceToHost, ms[0]->stream)) != hipSuccess) return dev_fail(0, "download", e);
+    if ((e = hipStreamSynchronize(ms[0]->stream)) != hipSuccess) return dev_fail(0, "the render failed on a device", e);   // the one synchronisation of the call
     return RTC_OK;
 }
 

@@ -39,6 +39,11 @@ struct ImageDesc { int width, height; uint32_t offset, pad; };                  
 // `count` (1..8) consecutive slots of bleaves / leaf_prims starting at `first`.
 struct alignas(16) BvhNode { float lo0[3]; int child0; float hi0[3]; int count0; float lo1[3]; int child1; float hi1[3]; int count1; };
 enum { RTC_BVH_EMPTY = (int)0x80000000, RTC_BVH_MAX_DEPTH = 64 };
+// The same node as the GPU reads it: every child box as CENTRE and HALF-EXTENT (rounded outward at upload, rtc_api.cpp).  The slab
+// test is then three FMAs per axis -- m = c * inv - o * inv, near = m - h |inv|, far = m + h |inv| -- with no per-axis min / max:
+// on gfx950 v_min_f32 / v_max_f32 (like v_cmp and v_cndmask) issue in 4 SIMD-cycles, an FMA in 2.2 (tools/ubench/valu_issue,
+// profiles/r03b_valu_issue.txt), and the lo / hi form spent two thirds of a node step's cycles on them.
+struct alignas(16) BvhNodeCH { float c0[3]; int child0; float h0[3]; int count0; float c1[3]; int child1; float h1[3]; int count1; };
 inline int rtc_leaf_ref(int first, int count) { return ~((first << 3) | (count - 1)); }
 // Traversal leaf of the FP32 production BVH: 64 bytes, the size of a node, so a lane fetches "what it stands on" with the
 // same four 16-byte loads whether that is a node or a leaf.  Stored in BVH leaf order (slot s of bleaves is primitive
@@ -77,7 +82,7 @@ template <typename R> struct SceneT {
     const LightT<R> *lights; int n_lights;
     const R *perlin_vec;     const int *perlin_perm;   // per noise slot: 768 reals, 768 ints
     const ImageDesc *images; const unsigned char *image_data;
-    const BvhNode *nodes;    const int *leaf_prims; int n_nodes;   // n_nodes == 0: brute-force loop over prims
+    const BvhNodeCH *nodes;  const int *leaf_prims; int n_nodes;   // n_nodes == 0: brute-force loop over prims
     const BLeaf *bleaves;                                          // FP32 production BVH only (NULL in the FP64 tables)
     const struct SmallShade *leaf_shade;                           // per leaf slot: everything shading needs of a resolved leaf, one 48-byte read
     int bvh_root;            // where a traversal starts: node 0, or the leaf run itself when the whole scene is one leaf (its node's second child is RTC_BVH_EMPTY and its box is never tested)

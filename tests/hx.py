@@ -133,6 +133,13 @@ class Harness:
         self.lib.hx_render_refloop(C.c_int(w), C.c_int(h), C.c_int(spp), C.c_int(depth), px.ctypes.data_as(_bp))
         return px
 
+    def render_refloop_omp(self, w, h, spp, depth, threads=16, seed=1):
+        """The reference's loop as shipped: 16 row chunks under `omp parallel for`, one shared rand() (timing row only)."""
+        px = np.zeros((h, w, 3), dtype=np.uint8)
+        self.srand(seed)
+        self.lib.hx_render_refloop_omp(C.c_int(w), C.c_int(h), C.c_int(spp), C.c_int(depth), C.c_int(threads), px.ctypes.data_as(_bp))
+        return px
+
     # -- unit probes ---------------------------------------------------------------------------
     def _hit_probe(self, fn, params, rays, tmin, tmax):
         params, pp = _d(params)

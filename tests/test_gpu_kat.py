@@ -1,5 +1,5 @@
 """GPU: device-level known-answer tests of the shading functions and the generator the production kernels call, and
-ray_color for supplied rays (rtc_kat / rtc_ray_colors, include/rtc.h).
+ray_color for supplied rays (rtc_kat, include/rtc_test.h; rtc_ray_colors, include/rtc.h).
 
 The expected values are the REFERENCE's own outputs for the same inputs (tests/golden/unit_vectors.npz, produced by the
 compiled 03_FullTracer) or the oracle's pinned functions; the device computes in FP32 with hardware rcp / rsq / sqrt /

@@ -276,6 +276,48 @@ def test_wavefront_renders_on_two_streams_share_the_pool_in_order(gpu):
         sc.close()
 
 
+def test_wavefront_render_only_enqueues_and_its_parts_add_up(gpu, monkeypatch):
+    """rtc_render_device for a BVH scene puts a fixed bounce schedule on the stream and returns (rtc_api.cpp render_wavefront: the list
+    length, the compaction decision and the end of the render are device-side state; nothing is read back): the call comes back while
+    the stream is still busy, in a fraction of the time the render takes.  The samples run as up to three parts on streams of their
+    own (RTC_WF_PARTS is the A/B knob): same Philox counters, so one part and three parts agree to FP32 reassociation (1e-5 relative),
+    the ray counts are equal, and the same call twice is bit-identical."""
+    import time
+    import torch
+    from raytracer_amd import dist as rd
+    sc, cam, view = gpu.build_named_scene("final")
+    try:
+        W = H = 512
+        st = gpu.Settings(W, H, 256, view.max_depth, view.integrator, seed=5)
+        side = torch.cuda.Stream()
+        out = {}
+        for parts in ("3", "1", "3"):
+            monkeypatch.setenv("RTC_WF_PARTS", parts)
+            acc = rd.new_accum(H, W, "cuda:0")
+            with torch.cuda.stream(side):
+                rd.render_into(sc, cam, gpu.Settings(W, H, 8, view.max_depth, view.integrator, seed=5), rd.new_accum(H, W, "cuda:0"))   # the pool is allocated here
+            torch.cuda.synchronize()
+            with torch.cuda.stream(side):
+                t0 = time.perf_counter()
+                rd.render_into(sc, cam, st, acc)
+                t1 = time.perf_counter()
+                busy_at_return = not side.query()
+            side.synchronize()
+            t2 = time.perf_counter()
+            stats = sc.stats(side.cuda_stream)
+            print(f"parts {parts}: call {1e3 * (t1 - t0):.2f} ms, render {1e3 * (t2 - t0):.2f} ms, kernel {stats['kernel_ms']:.2f} ms")
+            assert busy_at_return and (t1 - t0) < 0.5 * (t2 - t0)
+            assert stats["kernel_used"] == 3 and stats["samples"] == W * H * 256
+            out.setdefault(parts, []).append((acc.cpu().numpy(), stats["rays"]))
+        (a3, r3), (b3, rb3) = out["3"]
+        a1, r1 = out["1"][0]
+        assert np.array_equal(a3, b3) and r3 == rb3
+        assert r1 == r3 and (a1[..., 3] == 256).all() and (a3[..., 3] == 256).all()
+        assert np.allclose(a1[..., :3], a3[..., :3], rtol=1e-5, atol=1e-4)
+    finally:
+        sc.close()
+
+
 @pytest.mark.parametrize("name,integrator,blk_tol", [("cornell", 0, 0.004), ("simple", 0, 0.004), ("cornell02", 1, 0.008)])
 def test_small_scene_kernel_agrees_with_general_kernel(gpu, name, integrator, blk_tol):
     """kernel=2 (packed leaves, LDS shading records, basis-free cosine sampling) and kernel=1 (general megakernel) are

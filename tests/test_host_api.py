@@ -192,11 +192,24 @@ def test_png_rows_and_sizes_round_trip(rtc, tmp_path):
         assert np.array_equal(np.asarray(Image.open(p).convert("RGB")), img[::-1])
 
 
+def test_last_error_is_the_latest_error_on_the_thread(rtc):
+    """rtc_last_error after a refusal of the allocation-free entry point (its messages are string literals: that path must not touch
+    the heap) followed by another failure on the same thread: the later message wins (every setter clears the literal)."""
+    L = rtc.lib()
+    assert L.rtc_render_device_noalloc(None, None, None, None, None) != 0
+    assert b"rtc_render_device_noalloc" in L.rtc_last_error()
+    assert not L.rtc_scene_load(b"/nonexistent/dir/scene.rtcscene")
+    assert b"rtc_scene_load" in L.rtc_last_error() and b"noalloc" not in L.rtc_last_error()
+    assert L.rtc_render_device_noalloc(None, None, None, None, None) != 0
+    assert L.rtc_scene_save(None, None) != 0
+    assert b"rtc_scene_save" in L.rtc_last_error()
+
+
 def test_every_declared_symbol_is_exported(rtc):
     """include/*.h vs librtc.so: every prototype in the headers resolves in the shared library."""
     L = rtc.lib()
     names = set()
-    for hdr in ("raytracer.h", "rtc.h"):
+    for hdr in ("raytracer.h", "rtc.h", "rtc_test.h"):
         src = open(os.path.join(ROOT, "include", hdr)).read()
         src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
         names |= set(re.findall(r"\b(\w+)\s*\([^;{]*\)\s*;", src))

@@ -35,6 +35,8 @@ def test_noalloc_entry_matches_render_device_on_two_calls_in_a_row(gpu):
             assert rc == 0, L.rtc_last_error()
             got.append(acc)
         torch.cuda.synchronize()
+        assert torch.cuda.mem_get_info()[0] == free0                     # nothing was allocated on the device by the three calls (the
+                                                                         # accumulators come out of torch's cached blocks: torch.full above)
         for g, w, st in zip(got, want, jobs):
             g = g.cpu().numpy()
             assert (g[..., 3] == st.c.sample_end - st.c.sample_begin).all()
@@ -67,6 +69,27 @@ def test_noalloc_entry_matches_render_device_on_two_calls_in_a_row(gpu):
         assert L.rtc_render_device_noalloc(sc.handle, cam.handle, C.byref(st_a.c), host.ctypes.data, None) != 0
         assert b"device memory" in L.rtc_last_error()
         assert L.rtc_render_device_noalloc(sc.handle, cam.handle, None, acc.data_ptr(), None) != 0
+        # under HIP graph capture: a captured call must not allocate, synchronise or query -- capture fails if it does; the replay
+        # renders the same image as the eager call
+        st_g = gpu.Settings(203, 117, 0, 10, 0, seed=21, sample_begin=0, sample_end=32)
+        eager = torch.zeros((117, 203, 4), dtype=torch.float32, device="cuda:0")
+        assert L.rtc_render_device_noalloc(sc.handle, cam.handle, C.byref(st_g.c), eager.data_ptr(), None) == 0
+        torch.cuda.synchronize()
+        captured = torch.zeros_like(eager)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(side):
+            graph.capture_begin()
+            rc = L.rtc_render_device_noalloc(sc.handle, cam.handle, C.byref(st_g.c), captured.data_ptr(), side.cuda_stream)
+            graph.capture_end()
+        assert rc == 0, L.rtc_last_error()
+        torch.cuda.synchronize()
+        assert not captured.any()                                        # captured, not run
+        graph.replay(); torch.cuda.synchronize()
+        assert np.array_equal(captured.cpu().numpy(), eager.cpu().numpy())
+        graph.replay(); torch.cuda.synchronize()                         # the call ADDS: a second replay doubles the sums
+        assert np.array_equal(captured.cpu().numpy()[..., 3], 2 * eager.cpu().numpy()[..., 3])
     finally:
         sc.close()
     bvh, cam2, view2 = gpu.build_named_scene("book1")

@@ -371,9 +371,12 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RT_SMA
             h = small_closest_hit<fused>(ss, ro, rd, 0.001f, src, pdf_ray);  // ray.c:56
             ++nrays;
             if (fused && pend > 0.0f) {                               // complete the previous bounce: T *= pdf_cos / pdf_val (ray.c:80-83)
-                // (pend > 0 and a cosine weight > 0 make pdf_val > 0; a pdf_val of 0 or NaN -- cosine weight 0, a ray from inside a light
-                // sphere -- turns T into inf / NaN like the reference's 0/0, and a non-finite path sum is dropped where the path ends)
+                // (pend > 0 and a cosine weight > 0 make pdf_val > 0.  A pdf_val of 0 or NaN -- an underflowed mixture, a ray from inside a
+                // light sphere -- is the reference's 0/0: nothing more arrives from this path.  The stand-alone light loop ends such a path at
+                // the bounce that made the direction; here the direction's ray has just been traced to learn its pdf, so the path ends now,
+                // carrying nothing, and that one ray is not counted: both forms report the same paths and the same rays.)
                 const float pdf_val = P.light_weight_each * pdf_ray + P.cosine_weight * pend;
+                if (!(pdf_val > 0.0f)) { alive = false; --nrays; }
                 T = T * (pend * __builtin_amdgcn_rcpf(pdf_val));
                 pend = 0.0f;
             }

@@ -17,6 +17,79 @@ constexpr int ITERS = 16384;
 // eight accumulators pinned to v[8..15] and two operands to chosen registers, so that the bank of every source is known
 #define BODY8(INSTR) INSTR(8) INSTR(9) INSTR(10) INSTR(11) INSTR(12) INSTR(13) INSTR(14) INSTR(15)
 #define REP8(X) X X X X X X X X
+
+// second batch (round 3): one template per instruction form, D = accumulator register, A / B = operand registers
+#define GROUP(T) T(8, 17, 18) T(9, 18, 19) T(10, 19, 16) T(11, 16, 17) T(12, 17, 18) T(13, 18, 19) T(14, 19, 16) T(15, 16, 17)
+#define GROUP4(T) T(8, 9, 16, 17, 18, 19) T(10, 11, 16, 17, 18, 19) T(12, 13, 16, 17, 18, 19) T(14, 15, 16, 17, 18, 19)
+#define ACC8 "v8", "v9", "v10", "v11", "v12", "v13", "v14", "v15"
+#define T_ADD_U32(D, A, B) "v_add_u32 v" #D ", v" #D ", v" #A "\n"
+#define T_LSHL(D, A, B) "v_lshlrev_b32 v" #D ", 1, v" #D "\n"
+#define T_LSHR(D, A, B) "v_lshrrev_b32 v" #D ", 1, v" #D "\n"
+#define T_AND(D, A, B) "v_and_b32 v" #D ", v" #D ", v" #A "\n"
+#define T_MUL_LO(D, A, B) "v_mul_lo_u32 v" #D ", v" #D ", v" #A "\n"
+#define T_MUL_HI(D, A, B) "v_mul_hi_u32 v" #D ", v" #D ", v" #A "\n"
+#define T_MAD64(D, E, A, B, C, F) "v_mad_u64_u32 v[" #D ":" #E "], vcc, v" #D ", v" #A ", v[" #C ":" #F "]\n"
+#define T_RCP(D, A, B) "v_rcp_f32 v" #D ", v" #D "\n"
+#define T_SQRT(D, A, B) "v_sqrt_f32 v" #D ", v" #D "\n"
+#define T_RSQ(D, A, B) "v_rsq_f32 v" #D ", v" #D "\n"
+#define T_SIN(D, A, B) "v_sin_f32 v" #D ", v" #D "\n"
+#define T_EXP(D, A, B) "v_exp_f32 v" #D ", v" #D "\n"
+#define T_CVT(D, A, B) "v_cvt_f32_u32 v" #D ", v" #D "\n"
+#define T_BFE(D, A, B) "v_bfe_u32 v" #D ", v" #D ", v" #A ", v" #B "\n"
+#define T_PERM(D, A, B) "v_perm_b32 v" #D ", v" #D ", v" #A ", v" #B "\n"
+#define T_AND_OR(D, A, B) "v_and_or_b32 v" #D ", v" #D ", v" #A ", v" #B "\n"
+#define T_LSHL_ADD(D, A, B) "v_lshl_add_u32 v" #D ", v" #D ", 1, v" #A "\n"
+#define T_ADD3(D, A, B) "v_add3_u32 v" #D ", v" #D ", v" #A ", v" #B "\n"
+#define T_PK_FMA_S(D, E, A, B, C, F) "v_pk_fma_f32 v[" #D ":" #E "], %0, v[" #A ":" #B "], v[" #D ":" #E "]\n"
+#define T_PK_FMA_SEL(D, E, A, B, C, F) "v_pk_fma_f32 v[" #D ":" #E "], %0, v[" #A ":" #B "], v[" #D ":" #E "] op_sel_hi:[1,0,1]\n"
+#define T_PK_MUL(D, E, A, B, C, F) "v_pk_mul_f32 v[" #D ":" #E "], v[" #D ":" #E "], v[" #A ":" #B "]\n"
+#define T_PK_ADD(D, E, A, B, C, F) "v_pk_add_f32 v[" #D ":" #E "], v[" #D ":" #E "], v[" #C ":" #F "]\n"
+#define T_PK_MUL_S(D, E, A, B, C, F) "v_pk_mul_f32 v[" #D ":" #E "], v[" #D ":" #E "], %0\n"
+#define T_ADD_ABS(D, A, B) "v_add_f32 v" #D ", |v" #D "|, v" #A "\n"
+#define T_FMA_NEG(D, A, B) "v_fma_f32 v" #D ", -v" #D ", v" #A ", v" #B "\n"
+#define T_MOV_S(D, A, B) "v_mov_b32 v" #D ", %0\n"
+#define T_MOV_LIT(D, A, B) "v_mov_b32 v" #D ", 0x12345678\n"
+#define T_CND_VCC(D, A, B) "v_cndmask_b32 v" #D ", v" #D ", v" #A ", vcc\n"
+#define T_MIN(D, A, B) "v_min_f32 v" #D ", v" #D ", v" #A "\n"
+#define T_ADD_F32(D, A, B) "v_add_f32 v" #D ", v" #D ", v" #A "\n"
+#define T_FMAC_S(D, A, B) "v_fmac_f32 v" #D ", %0, v" #A "\n"
+#define T_CMP_CLASS(D, A, B) "v_cmp_class_f32 vcc, v" #D ", v" #A "\n"
+#define T_CMP_U32(D, A, B) "v_cmp_ne_u32 vcc, v" #D ", v" #A "\n"
+#define T_CMP_S(D, A, B) "v_cmp_lt_f32 vcc, %0, v" #D "\n"
+#define T_MUL_DPP(D, A, B) "v_mul_f32_dpp v" #D ", v" #D ", v" #A " quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
+#define T_MUL_U24(D, A, B) "v_mul_u32_u24 v" #D ", v" #D ", v" #A "\n"
+#define T_MAD_U24(D, A, B) "v_mad_u32_u24 v" #D ", v" #D ", v" #A ", v" #B "\n"
+#define T_XOR_S(D, A, B) "v_xor_b32 v" #D ", %0, v" #D "\n"
+#define T_BFI(D, A, B) "v_bfi_b32 v" #D ", v" #A ", v" #D ", v" #B "\n"
+#define T_MUL_LEGACY(D, A, B) "v_mul_legacy_f32 v" #D ", v" #D ", v" #A "\n"
+#define T_MAX_S(D, A, B) "v_max_f32 v" #D ", %0, v" #D "\n"
+#define T_CVT_PK(D, A, B) "v_cvt_pkrtz_f16_f32 v" #D ", v" #D ", v" #A "\n"
+#define T_FMA_F16(D, A, B) "v_pk_fma_f16 v" #D ", v" #D ", v" #A ", v" #B "\n"
+#define T_LDEXP(D, A, B) "v_ldexp_f32 v" #D ", v" #D ", v" #A "\n"
+#define T_FRACT(D, A, B) "v_fract_f32 v" #D ", v" #D "\n"
+#define T_FLOOR(D, A, B) "v_floor_f32 v" #D ", v" #D "\n"
+#define T_CMP_CND_VCC(D, A, B) "v_cmp_lt_f32 vcc, v" #D ", v" #A "\n v_cndmask_b32 v" #D ", v" #D ", v" #B ", vcc\n"
+#define T_CMP_CND_S(D, A, B) "v_cmp_lt_f32 s[20:21], v" #D ", v" #A "\n v_cndmask_b32 v" #D ", v" #D ", v" #B ", s[20:21]\n"
+#define T_CND_VCC_E64(D, A, B) "v_cndmask_b32_e64 v" #D ", v" #D ", v" #A ", vcc\n"
+#define T_CND_VCC_OTHER(D, A, B) "v_cndmask_b32 v" #D ", v" #A ", v" #B ", vcc\n"
+#define T_CMP_CND2(D, A, B) "v_cmp_lt_f32 vcc, v" #D ", v" #A "\n v_cndmask_b32 v" #D ", v" #D ", v" #B ", vcc\n v_cndmask_b32 v" #D ", v" #D ", v" #A ", vcc\n"
+#define T_CMP_CND3(D, A, B) "v_cmp_lt_f32 vcc, v" #D ", v" #A "\n v_cndmask_b32 v" #D ", v" #D ", v" #B ", vcc\n v_cndmask_b32 v" #D ", v" #D ", v" #A ", vcc\n v_cndmask_b32 v" #D ", v" #D ", v" #B ", vcc\n"
+#define T_CND_MUL(D, A, B) "v_cndmask_b32 v" #D ", v" #D ", v" #B ", vcc\n v_mul_f32 v" #D ", v" #D ", v" #A "\n"
+#define T_CND_MUL3(D, A, B) "v_cndmask_b32 v" #D ", v" #D ", v" #B ", vcc\n v_mul_f32 v" #D ", v" #D ", v" #A "\n v_mul_f32 v" #D ", v" #D ", v" #A "\n v_mul_f32 v" #D ", v" #D ", v" #A "\n"
+#define T_ADDC(D, A, B) "v_addc_co_u32 v" #D ", vcc, v" #D ", v" #A ", vcc\n"
+#define T_CND_NOP(D, A, B) "v_cndmask_b32 v" #D ", v" #D ", v" #B ", vcc\n s_nop 0\n"
+#define T_CND_NOP1(D, A, B) "v_cndmask_b32 v" #D ", v" #D ", v" #B ", vcc\n s_nop 1\n"
+#define T_CND_VNOP(D, A, B) "v_cndmask_b32 v" #D ", v" #D ", v" #B ", vcc\n v_nop\n"
+#define T_CND_E32_E64(D, A, B) "v_cndmask_b32_e32 v" #D ", v" #D ", v" #B ", vcc\n v_cndmask_b32_e64 v" #D ", v" #D ", v" #A ", s[20:21]\n"
+#define T_CND_SALU(D, A, B) "v_cndmask_b32 v" #D ", v" #D ", v" #B ", vcc\n s_mov_b32 s22, s23\n"
+#define T_CND_IMUL(D, A, B) "v_cndmask_b32 v" #D ", v" #D ", v" #B ", vcc\n v_mul_f32 v20, v20, v" #A "\n"
+#define T_CND_IMOV(D, A, B) "v_cndmask_b32 v" #D ", v" #D ", v" #B ", vcc\n v_mov_b32 v20, v" #A "\n"
+#define T_CND_CMPS(D, A, B) "v_cndmask_b32 v" #D ", v" #D ", v" #B ", vcc\n v_cmp_lt_f32 s[20:21], v" #D ", v" #A "\n"
+#define T_CND2_MUL(D, A, B) "v_cndmask_b32 v" #D ", v" #D ", v" #B ", vcc\n v_cndmask_b32 v20, v20, v" #A ", vcc\n v_mul_f32 v" #D ", v" #D ", v" #A "\n"
+#define CASE_V(N, T) if (OP == N) { asm volatile(REP8(GROUP(T)) ::: ACC8, "vcc"); }
+#define CASE_S(N, T) if (OP == N) { asm volatile(REP8(GROUP(T)) :: "s"(seed) : ACC8, "vcc"); }
+#define CASE_P(N, T) if (OP == N) { asm volatile(REP8(GROUP4(T)) ::: ACC8, "vcc"); }
+#define CASE_PS(N, T) if (OP == N) { asm volatile(REP8(GROUP4(T)) :: "s"(mask) : ACC8, "vcc"); }
 template <int OP> __global__ void __launch_bounds__(256) k(unsigned long long *cycles, float *sink, float seed) {
     extern __shared__ int pin[];
     asm volatile("v_mov_b32 v8, %0\n v_mov_b32 v9, %0\n v_mov_b32 v10, %0\n v_mov_b32 v11, %0\n v_mov_b32 v12, %0\n v_mov_b32 v13, %0\n v_mov_b32 v14, %0\n v_mov_b32 v15, %0\n"
@@ -54,6 +127,23 @@ template <int OP> __global__ void __launch_bounds__(256) k(unsigned long long *c
         if (OP == 12) { asm volatile(REP8("v_cndmask_b32 v8, v8, v17, vcc\n v_cndmask_b32 v9, v9, v18, vcc\n v_cndmask_b32 v10, v10, v19, vcc\n v_cndmask_b32 v11, v11, v16, vcc\n v_cndmask_b32 v12, v12, v17, vcc\n v_cndmask_b32 v13, v13, v18, vcc\n v_cndmask_b32 v14, v14, v19, vcc\n v_cndmask_b32 v15, v15, v16, vcc\n") ::: "v8", "v9", "v10", "v11", "v12", "v13", "v14", "v15"); }
         if (OP == 13) { asm volatile(REP8("v_max3_f32 v8, v8, v17, v18\n v_max3_f32 v9, v9, v18, v19\n v_max3_f32 v10, v10, v19, v16\n v_max3_f32 v11, v11, v16, v17\n v_max3_f32 v12, v12, v17, v18\n v_max3_f32 v13, v13, v18, v19\n v_max3_f32 v14, v14, v19, v16\n v_max3_f32 v15, v15, v16, v17\n") ::: "v8", "v9", "v10", "v11", "v12", "v13", "v14", "v15"); }
         if (OP == 14) { asm volatile(REP8("v_cmp_lt_f32 vcc, v8, v17\n v_cmp_lt_f32 vcc, v9, v18\n v_cmp_lt_f32 vcc, v10, v19\n v_cmp_lt_f32 vcc, v11, v16\n v_cmp_lt_f32 vcc, v12, v17\n v_cmp_lt_f32 vcc, v13, v18\n v_cmp_lt_f32 vcc, v14, v19\n v_cmp_lt_f32 vcc, v15, v16\n") ::: "vcc"); }
+        CASE_V(30, T_ADD_U32) CASE_V(31, T_LSHL) CASE_V(32, T_LSHR) CASE_V(33, T_AND) CASE_V(34, T_MUL_LO) CASE_V(35, T_MUL_HI) CASE_P(36, T_MAD64)
+        CASE_V(37, T_RCP) CASE_V(38, T_SQRT) CASE_V(39, T_RSQ) CASE_V(40, T_SIN) CASE_V(41, T_EXP) CASE_V(42, T_CVT) CASE_V(43, T_BFE) CASE_V(44, T_PERM)
+        CASE_V(45, T_AND_OR) CASE_V(46, T_LSHL_ADD) CASE_V(47, T_ADD3) CASE_PS(48, T_PK_FMA_S) CASE_PS(49, T_PK_FMA_SEL) CASE_P(50, T_PK_MUL) CASE_P(51, T_PK_ADD)
+        CASE_PS(52, T_PK_MUL_S) CASE_V(53, T_ADD_ABS) CASE_V(54, T_FMA_NEG) CASE_S(55, T_MOV_S) CASE_V(56, T_MOV_LIT) CASE_V(57, T_CND_VCC) CASE_V(58, T_MIN)
+        CASE_V(59, T_ADD_F32) CASE_S(60, T_FMAC_S) CASE_V(61, T_CMP_CLASS) CASE_V(62, T_CMP_U32) CASE_S(63, T_CMP_S) CASE_V(64, T_MUL_DPP) CASE_V(65, T_MUL_U24)
+        CASE_V(66, T_MAD_U24) CASE_S(67, T_XOR_S) CASE_V(68, T_BFI) CASE_V(69, T_MUL_LEGACY) CASE_S(70, T_MAX_S) CASE_V(71, T_CVT_PK) CASE_V(72, T_FMA_F16)
+        CASE_V(76, T_CMP_CND_VCC) CASE_V(78, T_CND_VCC_E64) CASE_V(79, T_CND_VCC_OTHER)
+        if (OP == 77) { asm volatile(REP8(GROUP(T_CMP_CND_S)) ::: ACC8, "s20", "s21"); }
+        CASE_V(80, T_CMP_CND2) CASE_V(81, T_CMP_CND3) CASE_V(82, T_CND_MUL) CASE_V(83, T_CND_MUL3) CASE_V(84, T_ADDC)
+        CASE_V(85, T_CND_NOP) CASE_V(86, T_CND_NOP1) CASE_V(87, T_CND_VNOP)
+        if (OP == 88) { asm volatile(REP8(GROUP(T_CND_E32_E64)) ::: ACC8, "s20", "s21"); }
+        if (OP == 89) { asm volatile(REP8(GROUP(T_CND_SALU)) ::: ACC8, "s22", "s23"); }
+        if (OP == 90) { asm volatile(REP8(GROUP(T_CND_IMUL)) ::: ACC8, "v20"); }
+        if (OP == 91) { asm volatile(REP8(GROUP(T_CND_IMOV)) ::: ACC8, "v20"); }
+        if (OP == 92) { asm volatile(REP8(GROUP(T_CND_CMPS)) ::: ACC8, "s20", "s21"); }
+        if (OP == 93) { asm volatile(REP8(GROUP(T_CND2_MUL)) ::: ACC8, "v20"); }
+        CASE_V(73, T_LDEXP) CASE_V(74, T_FRACT) CASE_V(75, T_FLOOR)
     }
     const unsigned long long t1 = __builtin_readcyclecounter();
     float s; asm volatile("v_add_f32 %0, v8, v9\n v_add_f32 %0, %0, v10\n v_add_f32 %0, %0, v11\n v_add_f32 %0, %0, v12\n v_add_f32 %0, %0, v13\n v_add_f32 %0, %0, v14\n v_add_f32 %0, %0, v15\n" : "=v"(s));
@@ -113,5 +203,26 @@ int main() {
     run<22>("8 v_mul_f32 + 2 ds_read_b128 broadcast (per 8)", 64);
     run<8>("v_pk_fma_f32 (32 per iteration)", 32);
     run<10>("v_fma_f32, ONE dependent chain", 64);
+    printf("-- second batch --\n");
+    run<59>("v_add_f32 (VOP2)", 64); run<58>("v_min_f32 (VOP2)", 64); run<53>("v_add_f32 with |x| modifier (VOP3)", 64); run<54>("v_fma_f32 with a neg modifier", 64);
+    run<69>("v_mul_legacy_f32", 64); run<73>("v_ldexp_f32", 64); run<74>("v_fract_f32", 64); run<75>("v_floor_f32", 64);
+    run<60>("v_fmac_f32 with an SGPR source", 64); run<70>("v_max_f32 with an SGPR source", 64); run<67>("v_xor_b32 with an SGPR source", 64);
+    run<55>("v_mov_b32 from an SGPR", 64); run<56>("v_mov_b32 of a 32-bit literal", 64);
+    run<57>("v_cndmask_b32 (vcc), vcc declared", 64); run<61>("v_cmp_class_f32 -> vcc", 64); run<62>("v_cmp_ne_u32 -> vcc", 64); run<63>("v_cmp_lt_f32 (SGPR source) -> vcc", 64);
+    run<76>("v_cmp -> vcc + v_cndmask (vcc) pairs (per instr)", 128); run<77>("v_cmp -> s[20:21] + v_cndmask (s[20:21]) pairs", 128);
+    run<78>("v_cndmask_b32_e64 (vcc)", 64); run<79>("v_cndmask_b32 (vcc), dst not a source", 64);
+    run<80>("v_cmp -> vcc + 2 v_cndmask (vcc) (per instr)", 192); run<81>("v_cmp -> vcc + 3 v_cndmask (vcc) (per instr)", 256);
+    run<82>("v_cndmask (vcc) + v_mul pairs (per instr)", 128); run<83>("v_cndmask (vcc) + 3 v_mul (per instr)", 256); run<84>("v_addc_co_u32 (vcc in and out)", 64);
+    run<85>("v_cndmask (vcc) + s_nop 0 (per cndmask)", 64); run<86>("v_cndmask (vcc) + s_nop 1 (per cndmask)", 64); run<87>("v_cndmask (vcc) + v_nop (per cndmask)", 64);
+    run<88>("v_cndmask e32 (vcc) + e64 (s[20:21]) pairs (per instr)", 128); run<89>("v_cndmask (vcc) + s_mov_b32 (per cndmask)", 64);
+    run<90>("v_cndmask (vcc) + independent v_mul (per instr)", 128); run<91>("v_cndmask (vcc) + independent v_mov (per instr)", 128);
+    run<92>("v_cndmask (vcc) + v_cmp -> s[20:21] (per instr)", 128); run<93>("2 v_cndmask (vcc) + v_mul (per instr)", 192);
+    run<30>("v_add_u32", 64); run<31>("v_lshlrev_b32", 64); run<32>("v_lshrrev_b32", 64); run<33>("v_and_b32", 64); run<43>("v_bfe_u32", 64); run<68>("v_bfi_b32", 64); run<44>("v_perm_b32", 64);
+    run<45>("v_and_or_b32", 64); run<46>("v_lshl_add_u32", 64); run<47>("v_add3_u32", 64);
+    run<34>("v_mul_lo_u32", 64); run<35>("v_mul_hi_u32", 64); run<65>("v_mul_u32_u24", 64); run<66>("v_mad_u32_u24", 64); run<36>("v_mad_u64_u32 (32 per iteration)", 32);
+    run<37>("v_rcp_f32", 64); run<38>("v_sqrt_f32", 64); run<39>("v_rsq_f32", 64); run<40>("v_sin_f32", 64); run<41>("v_exp_f32", 64); run<42>("v_cvt_f32_u32", 64); run<71>("v_cvt_pkrtz_f16_f32", 64);
+    run<64>("v_mul_f32 with a DPP quad_perm source", 64);
+    run<50>("v_pk_mul_f32 (32 per iteration)", 32); run<51>("v_pk_add_f32 (32)", 32); run<48>("v_pk_fma_f32, SGPR-pair source (32)", 32); run<49>("v_pk_fma_f32, SGPR pair + op_sel_hi (32)", 32);
+    run<52>("v_pk_mul_f32, SGPR-pair source (32)", 32); run<72>("v_pk_fma_f16 (64)", 64);
     return 0;
 }

@@ -51,17 +51,18 @@ ALGO_HBM_BYTES_PER_PIXEL = 32     # float4 accumulator read + write once per lau
 SMALL_KERNEL_NAME = "k_pathtrace_small<0, false, false, true>"   # 03 integrator, pinhole, not the cost probe, light pdfs fused into the intersection
 GATHER_PEAK_L2, GATHER_PEAK_BIG = 207e9, 57e9   # measured: profiles/r02d/gather_rates.txt
 PEAK_L2_GBS = 34500.0             # MI355X_MICROARCH.md: 8 x 4 MiB L2, ~34.5 TB/s aggregate (HBM3E: 8 TB/s)
-# BVH scenes (wavefront kernels).  Per ray, measured with the RT_EXP=3/4 probe builds: node steps and leaf
-# steps of the production two-child tree.
-#   bytes/ray = (node steps + leaf steps) x 64 B (a node and a traversal leaf are both 64 B) + 166 B of path-slot state per
-#               bounce (extend 48 R + 9 W, shade 61 R + 48 W)
+# BVH scenes (wavefront kernels).  Per ray: node steps and leaf steps of the production two-child tree, counted by round 2's step-probe
+# builds (the probes left the product sources in round 3, the tree and the traversal order have not changed since).
+#   bytes/ray = (node steps + leaf steps) x 64 B (a node and a traversal leaf are both 64 B) + 101 B of path-slot state per
+#               bounce (extend with its shading tail: list entry 4 R, state 48 R + 48 W, key 1 W; round 2's separate shade stage
+#               made it 166 B)
 #   FLOP/ray  = node steps x 30 (two aabb slab tests, aabb.c:33-63 at 15 each) + leaf steps x leaf test (sphere 26,
 #               hittable.c:406-429; rect 6; a box record's slab ~18: scene average) + everything that is not traversal, from
 #               the instrumented oracle run of tests/flop_model.py on the same scene (hit records, media, textures, materials,
 #               camera): final 128.1, final_earth 119.4, book1 32.8
 # Which roof: final / final_earth / book1 keep their trees (<= 285 KB) in L2 and are bound by VALU issue under divergence
-# (profiles/r02b: extend active-lane 0.23, wait 0.49) -> "valu"; the 1M-sphere tree (105 MB) is served by L2 + Infinity Cache
-# (TCC hit rate 0.55, wait 0.68) -> "l2", with the L2 requests counted by rocprofv3 beside the algorithmic bytes.
+# (profiles/r03a/final: extend active-lane 0.24, wait 0.55) -> "valu"; the 1M-sphere tree (105 MB) is served by L2 + Infinity Cache
+# (profiles/r03a/million: TCC hit rate 0.55) -> "l2", with the L2 requests counted by rocprofv3 beside the algorithmic bytes.
 SCENE_MODEL = {
     "final":       dict(node_steps=10.4, leaf_steps=3.3, leaf_flop=22, other_flop=128.1, bound="valu"),
     "final_earth": dict(node_steps=10.0, leaf_steps=2.7, leaf_flop=22, other_flop=119.4, bound="valu"),
@@ -69,7 +70,7 @@ SCENE_MODEL = {
     "million":     dict(node_steps=23.6, leaf_steps=2.7, leaf_flop=26, other_flop=32.8, bound="l2"),
 }
 for _m in SCENE_MODEL.values():
-    _m["bytes_per_ray"] = (_m["node_steps"] + _m["leaf_steps"]) * 64 + 166
+    _m["bytes_per_ray"] = (_m["node_steps"] + _m["leaf_steps"]) * 64 + 101
     _m["flop_per_ray"] = _m["node_steps"] * 30 + _m["leaf_steps"] * _m["leaf_flop"] + _m["other_flop"]
 SCENE_BYTES = {k: v["bytes_per_ray"] for k, v in SCENE_MODEL.items()}
 WORKLOADS = {"final": "02_AdvancedTracer final scene", "final_earth": "02_AdvancedTracer final scene + earth-map globe",
@@ -79,7 +80,7 @@ WORKLOADS = {"final": "02_AdvancedTracer final scene", "final_earth": "02_Advanc
 def scene_roofline(scene, rays_per_launch, k_ms):
     """roofline object of a BVH scene: FP32 VALU roof where the kernels are issue bound, aggregate L2 where they wait for node fetches."""
     m = SCENE_MODEL[scene]
-    common = {"kernel": "k_wf_extend + k_wf_shade", "kernel_ms": k_ms, "rays_per_launch": rays_per_launch,
+    common = {"kernel": "k_wf_extend (traversal + shading tail) + k_wf_shade (textured hits)", "kernel_ms": k_ms, "rays_per_launch": rays_per_launch,
               "algorithmic_flop_per_ray": m["flop_per_ray"], "algorithmic_bytes_per_ray": m["bytes_per_ray"],
               "node_steps_per_ray": m["node_steps"], "leaf_steps_per_ray": m["leaf_steps"]}
     # second wall of the traversal (DESIGN.md 3.2, profiles/r02d): 64-byte node / leaf records fetched at random; the gather loop of
@@ -96,12 +97,12 @@ def scene_roofline(scene, rays_per_launch, k_ms):
 
 
 def measured_l2_requests(scene):
-    """TCC_HIT + TCC_MISS of k_wf_extend per launch from the committed rocprofv3 pass of this scene (profiles/r02b), or None."""
+    """TCC_HIT + TCC_MISS of k_wf_extend per launch from the committed rocprofv3 pass of this scene (profiles/r03a), or None."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r02b", scene, "summary.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r03a", scene, "summary.json")) as f:
             s = json.load(f)
         p = s["pmc_per_launch"]
-        return {"profile": "r02b/" + scene, "kernel": s.get("kernel"), "tcc_hit_per_launch": p["TCC_HIT_sum"], "tcc_miss_per_launch": p["TCC_MISS_sum"],
+        return {"profile": "r03a/" + scene, "kernel": s.get("kernel"), "tcc_hit_per_launch": p["TCC_HIT_sum"], "tcc_miss_per_launch": p["TCC_MISS_sum"],
                 "hit_rate": p["TCC_HIT_sum"] / (p["TCC_HIT_sum"] + p["TCC_MISS_sum"]), "kernel_ms": s.get("avg_ms")}
     except (OSError, KeyError, ValueError, ZeroDivisionError):
         return None

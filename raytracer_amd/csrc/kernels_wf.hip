@@ -329,9 +329,13 @@ __global__ void __launch_bounds__(kWfLdsBlock) __attribute__((amdgpu_waves_per_e
 // by (material type, texture type) of what they hit, so a wave runs one arm of the material switch instead of all of them.
 // Only slot ids move; no global atomics; the order of the work is a function of the list alone.
 constexpr int kWfShadeBlock = 1024;
+#ifndef RT_WF_SHADE_WAVES
+#define RT_WF_SHADE_WAVES 5      // resident waves per SIMD (96 VGPRs: no spills in either variant; 6 waves measured the same within 0.5 %)
+#endif
 template <bool NOISE>
-__global__ void __launch_bounds__(kWfShadeBlock) __attribute__((amdgpu_waves_per_eu(NOISE ? 5 : 6))) k_wf_shade(SceneT<float> sc, CameraT<float> cam, RenderParams P, WfBuffers B) {
+__global__ void __launch_bounds__(kWfShadeBlock) __attribute__((amdgpu_waves_per_eu(RT_WF_SHADE_WAVES))) k_wf_shade(WfArgs a) {
     constexpr unsigned N = kWfShadeBlock;
+    const WfBuffers &B = a.B;
     if (B.counters[WF_LIVE] == 0) return;
     const unsigned n_list = B.counters[WF_NLIST]; const int cur = (int)B.counters[WF_CUR];
     __shared__ int q_slot[2 * N];
@@ -380,13 +384,14 @@ __global__ void __launch_bounds__(kWfShadeBlock) __attribute__((amdgpu_waves_per
             q_n = rest;
             bool died = false;
             if (tid < take) {
+                const WfArgs &t = wf_args_again(c);                  // scene, camera and render parameters: read here, not held across the scan
                 const int slot = sorted_slot[tid];
-                const float4 o = B.ro[slot], d = B.rd[slot], tm = B.tm[slot];
-                int px, py, layer; slot_pixel(P, B, slot, px, py, layer);
-                const float2 hh = B.hit[slot];
+                const float4 o = t.B.ro[slot], d = t.B.rd[slot], tm = t.B.tm[slot];
+                int px, py, layer; slot_pixel(t.P, t.B, slot, px, py, layer);
+                const float2 hh = t.B.hit[slot];
                 SmallShade none; none.meta = 0;
-                died = wf_shade_entry<NOISE, true>(sc, cam, P, B, slot, px, py, o, d, tm, hh.x, __float_as_int(hh.y), none);
-                if (died) B.active[cur][sorted_index[tid]] = -1;     // stays in the list as a hole until the next compaction
+                died = wf_shade_entry<NOISE, true>(t.sc, t.cam, t.P, t.B, slot, px, py, o, d, tm, hh.x, __float_as_int(hh.y), none);
+                if (died) t.B.active[cur][sorted_index[tid]] = -1;   // stays in the list as a hole until the next compaction
             }
             wave_count_sub(B.counters + 0, died);
             __syncthreads();                                         // sorted_* and the queue are free again
@@ -490,8 +495,8 @@ hipError_t launch_wf_bounce(const SceneT<float> &sc, const CameraT<float> &cam, 
     else hipLaunchKernelGGL((k_wf_extend<2, RTC_KIND_ALL>), dim3(blocks), dim3(kWfExtendBlock), lds, stream, args);
     if (sc.n_general == 0) return hipGetLastError();               // every hit was shaded in extend's tail
     const dim3 sgrid(std::min((n_max + kWfShadeBlock - 1) / kWfShadeBlock, n_cus));   // persistent: one 1024-thread workgroup per CU
-    if (sc.tex_kinds & (1 << RTC_TEX_NOISE)) hipLaunchKernelGGL(k_wf_shade<true>, sgrid, dim3(kWfShadeBlock), 0, stream, sc, cam, p, b);
-    else hipLaunchKernelGGL(k_wf_shade<false>, sgrid, dim3(kWfShadeBlock), 0, stream, sc, cam, p, b);
+    if (sc.tex_kinds & (1 << RTC_TEX_NOISE)) hipLaunchKernelGGL(k_wf_shade<true>, sgrid, dim3(kWfShadeBlock), 0, stream, args);
+    else hipLaunchKernelGGL(k_wf_shade<false>, sgrid, dim3(kWfShadeBlock), 0, stream, args);
     return hipGetLastError();
 }
 hipError_t launch_wf_compact(const WfBuffers &b, hipStream_t stream) {

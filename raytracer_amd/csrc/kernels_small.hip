@@ -35,67 +35,63 @@ namespace {
 
 struct SmallHit { float t; int leaf; };
 
-RT_DEV f3 xform_point(const SmallXform &x, f3 p) {
-    return f3mk(x.m[0] * p.x + x.m[1] * p.y + x.m[2] * p.z + x.b[0], x.m[3] * p.x + x.m[4] * p.y + x.m[5] * p.z + x.b[1],
-                x.m[6] * p.x + x.m[7] * p.y + x.m[8] * p.z + x.b[2]);
-}
-RT_DEV f3 xform_dir(const SmallXform &x, f3 d) {
-    return f3mk(x.m[0] * d.x + x.m[1] * d.y + x.m[2] * d.z, x.m[3] * d.x + x.m[4] * d.y + x.m[5] * d.z, x.m[6] * d.x + x.m[7] * d.y + x.m[8] * d.z);
-}
+typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
+RT_DEV float recf(const u32x16 &R, int k) { return __uint_as_float(R[k]); }
 RT_DEV f3 rcp3(f3 d) { return f3mk(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z)); }
 
-// rect_hit (hittable.c:494-506) for the two rects of a SmallPair, ray already split into the run's normal (on, in = 1/dn)
-// and in-plane (oab, dab) parts.  All range tests fold into ONE compare: the largest violation
-//   max(lo - p, p - hi, tmin - t, t - tbest) <= 0
-// so no lane masks are combined on the (single, shared) scalar unit; packed FP32 math does both in-plane axes at once.
-// tbest starts at a large FINITE value: a t of +inf (dn == 0) then violates t - tbest, NaNs fail the compare.
+// rect_hit (hittable.c:494-506) for one rect of a pair record, the ray already split into the run's normal (on, in = 1/dn) and
+// in-plane (oa, da, ob, db) parts; the rect is centre (ca, cb) and half extent (ha, hb).  All range tests fold into ONE compare:
+// the largest violation  max(|pa - ca| - ha, |pb - cb| - hb, tmin - t, t - tbest) <= 0, so no lane masks are combined on the
+// scalar unit.  tbest starts at a large FINITE value: a t of +inf (dn == 0) then violates t - tbest, NaNs fail the compare.
 // A ray cannot hit the plane it leaves again: the leaf it starts on (src) is excluded -- in FP32 the start point is off the
 // plane by up to |k| 2^-24 (3e-5 at k = 555) and a grazing ray (|d_n| < 0.03) would meet it again at t >= tmin.
-// A rect that is also an entry of the lights list (P.f[12] / P.f[13] = 1 / area, flatten.cpp mark_small_lights; a wave-uniform
-// branch) adds its pdf for THIS ray to `pdf` on the way: hittable_pdf_value (hittable.c:772-788) is this very plane test with
-// tmin 1e-4 and no upper bound, value t^2 |1/d_n| / area for a unit direction (small_light_pdf_one below is the stand-alone form).
-// (Round 1 did the two in-plane axes of a rect test in packed FP32 instructions -- v_pk_fma_f32 ...: a packed instruction issues in 1.4x the
-// time of a plain one (tools/ubench/valu_rates) and every run paid six moves to build the aligned register pairs; the plain form
-// below measured 1-2 % faster on the headline render, 17.95 -> 17.57 ms, and the packed one was removed in round 3.)
+// A rect that is also an entry of the lights list (`light`: a bit of the record's head, a scalar branch) adds its pdf for THIS ray
+// to `pdf` on the way: hittable_pdf_value (hittable.c:772-788) is this very plane test with tmin 1e-4 and no upper bound, value
+// t^2 |1/d_n| / area for a unit direction (small_light_pdf_one below is the stand-alone form).
+// (Round 1 did the two in-plane axes in packed FP32 instructions; the plain form measured 1-2 % faster, 17.95 -> 17.57 ms, because
+// every run paid six moves to build the aligned register pairs; the packed one left the sources in round 3.)
 template <bool PDF>
-RT_DEV void small_rect(float k, float lo_a, float lo_b, float hi_a, float hi_b, int id, float inv_area, float on, float in, float oa, float da, float ob, float db,
+RT_DEV void small_rect(float k, float ca, float cb, float ha, float hb, int id, bool light, float inv_area, float on, float in, float oa, float da, float ob, float db,
                        float tmin, int src, SmallHit &h, float &pdf) {
     const float t = (k - on) * in;
-    const float pa = __builtin_fmaf(da, t, oa), pb = __builtin_fmaf(db, t, ob);
-    const float outside = fmaxf(fmaxf(lo_a - pa, pa - hi_a), fmaxf(lo_b - pb, pb - hi_b));
+    const float ea = fabsf(__builtin_fmaf(da, t, oa) - ca) - ha, eb = fabsf(__builtin_fmaf(db, t, ob) - cb) - hb;
+    const float outside = fmaxf(ea, eb);
     const float viol = fmaxf(outside, fmaxf(tmin - t, t - h.t));
     const bool hit = (viol <= 0.0f) & (id != src);
     h.t = hit ? t : h.t; h.leaf = hit ? id : h.leaf;
-    if (PDF && inv_area != 0.0f) pdf += fmaxf(outside, 0.0001f - t) <= 0.0f ? (t * t) * (fabsf(in) * inv_area) : 0.0f;
+    if (PDF && light) pdf += ((outside <= 0.0f) & (t >= 0.0001f)) ? (t * t) * (fabsf(in) * inv_area) : 0.0f;
+}
+// the two rects of a pair record; the caller has split the ray by the run's axis
+template <bool PDF>
+RT_DEV void small_pair(const u32x16 &R, float on, float in, float oa, float da, float ob, float db, float tmin, int src, SmallHit &h, float &pdf) {
+    const uint32_t head = R[0];
+    small_rect<PDF>(recf(R, 1), recf(R, 3), recf(R, 4), recf(R, 5), recf(R, 6), (int)((head >> 16) & 0xffu), (head & (1u << 11)) != 0, recf(R, 11), on, in, oa, da, ob, db, tmin, src, h, pdf);
+    if (head & (1u << 10))
+        small_rect<PDF>(recf(R, 2), recf(R, 7), recf(R, 8), recf(R, 9), recf(R, 10), (int)(head >> 24), (head & (1u << 12)) != 0, recf(R, 12), on, in, oa, da, ob, db, tmin, src, h, pdf);
 }
 template <bool PDF>
-RT_DEV void small_run(const SmallScene &ss, int first, int count, float on, float in, float oa, float da, float ob, float db, float tmin, int src, SmallHit &h, float &pdf) {
-    for (int p = first; p < first + count; ++p) {                 // wave-uniform: one s_load_dwordx16
-        const SmallPair &P = ss.pairs[p];
-        small_rect<PDF>(P.f[0], P.f[2], P.f[3], P.f[4], P.f[5], __float_as_int(P.f[10]), P.f[12], on, in, oa, da, ob, db, tmin, src, h, pdf);
-        if (__float_as_int(P.f[11]) >= 0)
-            small_rect<PDF>(P.f[1], P.f[6], P.f[7], P.f[8], P.f[9], __float_as_int(P.f[11]), P.f[13], on, in, oa, da, ob, db, tmin, src, h, pdf);
-    }
+RT_DEV void small_pair_any(const u32x16 &R, f3 o, f3 d, f3 inv, float tmin, int src, SmallHit &h, float &pdf) {
+    const uint32_t axis = (R[0] >> 8) & 3u;                            // in-plane axes: XY -> x, y   XZ -> x, z   YZ -> y, z
+    if (axis == RTC_AXIS_XY) small_pair<PDF>(R, o.z, inv.z, o.x, d.x, o.y, d.y, tmin, src, h, pdf);
+    else if (axis == RTC_AXIS_XZ) small_pair<PDF>(R, o.y, inv.y, o.x, d.x, o.z, d.z, tmin, src, h, pdf);
+    else small_pair<PDF>(R, o.x, inv.x, o.y, d.y, o.z, d.z, tmin, src, h, pdf);
 }
-// box_hit (hittable.c:521-523 = the list scan over the sides) as one slab test, also for a box with openings: the surface is entered at the largest
-// near-plane parameter and left at the smallest far-plane parameter; a ray that starts inside (or on) the box hits the
-// exit face.  The face gives the leaf id, so shading sees the same record as after six rect tests.
+// box_hit (hittable.c:521-523 = the list scan over the sides) as one slab test, also for a box with openings: the surface is entered
+// at the largest near-plane parameter and left at the smallest far-plane parameter; a ray that starts inside (or on) the box hits
+// the exit face.  The face gives the leaf id, so shading sees the same record as after six rect tests.
 // A ray that starts on a face (src) cannot hit that face again (rt_core.hpp box_leaf_t): not as the entry, not as the exit.
-RT_DEV void small_box(const SmallBox &B, f3 o, f3 inv, float tmin, int src, SmallHit &h) {
-    // (k - o) / d as one FMA per plane, k * inv + (-o * inv) (what slab_f32 does for the BVH boxes): the planes move by up to
-    // |o| 2^-24, the resolution of the FP32 origin itself; 0.9 % faster than (k - o) * inv (17.98 -> 17.83 ms, round 2)
-    const f3 noi = f3mk(-o.x * inv.x, -o.y * inv.y, -o.z * inv.z);
-    const float x0 = __builtin_fmaf(B.lo[0], inv.x, noi.x), x1 = __builtin_fmaf(B.hi[0], inv.x, noi.x);
-    const float y0 = __builtin_fmaf(B.lo[1], inv.y, noi.y), y1 = __builtin_fmaf(B.hi[1], inv.y, noi.y);
-    const float z0 = __builtin_fmaf(B.lo[2], inv.z, noi.z), z1 = __builtin_fmaf(B.hi[2], inv.z, noi.z);
-    const float nx = fminf(x0, x1), ny = fminf(y0, y1), nz = fminf(z0, z1);
-    const float fx = fmaxf(x0, x1), fy = fmaxf(y0, y1), fz = fmaxf(z0, z1);
+// Centre / half-extent form: near, far = (c - o) / d -+ h / |d| -- no per-axis min / max.  Faces: the axis that set the parameter
+// and, on it, the side the ray comes from -- code 2 axis + (d < 0) for the entry (lo face when d > 0), that code ^ 1 for the exit;
+// the code picks the face's id byte out of the record's two id words with one v_perm_b32.
+RT_DEV void small_box(const u32x16 &R, f3 o, f3 inv, float tmin, int src, SmallHit &h) {
+    const float tcx = __builtin_fmaf(recf(R, 3), inv.x, -o.x * inv.x), tcy = __builtin_fmaf(recf(R, 4), inv.y, -o.y * inv.y), tcz = __builtin_fmaf(recf(R, 5), inv.z, -o.z * inv.z);
+    const float hx = recf(R, 6) * fabsf(inv.x), hy = recf(R, 7) * fabsf(inv.y), hz = recf(R, 8) * fabsf(inv.z);
+    const float nx = tcx - hx, ny = tcy - hy, nz = tcz - hz, fx = tcx + hx, fy = tcy + hy, fz = tcz + hz;
     const float t_in = fmaxf(fmaxf(nx, ny), nz), t_out = fminf(fminf(fx, fy), fz);
-    // faces: the axis that set the parameter, and on that axis the plane met first (entry) or last (exit)
-    const int ax_in = nx == t_in ? 0 : (ny == t_in ? 1 : 2), ax_out = fx == t_out ? 0 : (fy == t_out ? 1 : 2);
-    const float inv_in = ax_in == 0 ? inv.x : (ax_in == 1 ? inv.y : inv.z), inv_out = ax_out == 0 ? inv.x : (ax_out == 1 ? inv.y : inv.z);
-    const uint32_t id_in = ((inv_in > 0.0f ? B.ids_lo : B.ids_hi) >> (8 * ax_in)) & 0xffu;
-    const uint32_t id_out = ((inv_out > 0.0f ? B.ids_hi : B.ids_lo) >> (8 * ax_out)) & 0xffu;
+    const uint32_t kx = (__float_as_uint(inv.x) >> 31) | 0x0c0c0c00u, ky = (__float_as_uint(inv.y) >> 31) | 0x0c0c0c02u, kz = (__float_as_uint(inv.z) >> 31) | 0x0c0c0c04u;
+    const uint32_t k_in = nx == t_in ? kx : (ny == t_in ? ky : kz), k_out = (fx == t_out ? kx : (fy == t_out ? ky : kz)) ^ 1u;
+    const uint32_t ids_hi = R[2];                                     // (a VGPR copy: v_perm_b32 may read one scalar operand)
+    const uint32_t id_in = __builtin_amdgcn_perm(ids_hi, R[1], k_in), id_out = __builtin_amdgcn_perm(ids_hi, R[1], k_out);
     // the entry point counts when it is in range and that face exists; otherwise (ray starts inside, or enters through an
     // opening) the exit point
     const bool enter = (t_in >= tmin) & (id_in != 0xffu) & (id_in != (uint32_t)src);
@@ -104,64 +100,81 @@ RT_DEV void small_box(const SmallBox &B, f3 o, f3 inv, float tmin, int src, Smal
     const bool hit = (t_in <= t_out) & (t >= tmin) & (t <= h.t) & (id != 0xffu) & (id != (uint32_t)src);
     h.t = hit ? t : h.t; h.leaf = hit ? (int)id : h.leaf;
 }
-// the records of one object space against the ray in that space
+// world space, closest-approach form (rt_core.hpp sphere_t<float>); |dw| = 1 (every ray of this kernel): the quadratic's a is 1.
+// `src` = leaf the ray starts on: a sphere left behind has the roots {0, 2 tc} (rt_core.hpp sphere_leave_t).
 template <bool PDF>
-RT_DEV void small_group_hit(const SmallScene &ss, const SmallGroup &g, f3 o, f3 d, f3 inv, float tmin, int src, SmallHit &h, float &pdf) {
-    if (g.box >= 0) small_box(ss.boxes[g.box], o, inv, tmin, src, h);
-    int first = g.first;
-    small_run<PDF>(ss, first, g.n_xy, o.z, inv.z, o.x, d.x, o.y, d.y, tmin, src, h, pdf); first += g.n_xy;
-    small_run<PDF>(ss, first, g.n_xz, o.y, inv.y, o.x, d.x, o.z, d.z, tmin, src, h, pdf); first += g.n_xz;
-    small_run<PDF>(ss, first, g.n_yz, o.x, inv.x, o.y, d.y, o.z, d.z, tmin, src, h, pdf);
+RT_DEV void small_sphere(const u32x16 &R, f3 ow, f3 dw, float tmin, int src, SmallHit &h, float &pdf) {
+    const uint32_t head = R[0];
+    const int id = (int)((head >> 8) & 0xffu);
+    const float r2 = recf(R, 4);
+    const f3 oc = ow - f3mk(recf(R, 1), recf(R, 2), recf(R, 3));
+    const float tc = -dot(oc, dw);
+    const f3 l = oc + dw * tc;
+    const float q = r2 - len2(l);
+    const float sq = __builtin_amdgcn_sqrtf(fmaxf(q, 0.0f));
+    const bool from = id == src;                                 // leaving this sphere: roots are {0, 2 tc}
+    const float t0 = from ? 2.0f * tc : tc - sq, t1 = tc + sq;
+    const bool ok0 = (t0 >= tmin) & (t0 <= h.t), ok1 = (t1 >= tmin) & (t1 <= h.t) & !from;
+    const float t = ok0 ? t0 : t1;
+    const bool hit = (from | (q >= 0.0f)) & (ok0 | ok1);
+    h.t = hit ? t : h.t; h.leaf = hit ? id : h.leaf;
+    if (PDF && (head & (1u << 16))) {                            // wave-uniform: this sphere is a light-list entry (hittable.c:760-768)
+        const float need = 0.001f - tc;                          // the far root tc + sqrt(q) decides alone: small_light_pdf_one
+        const bool seen = !(q < 0.0f) & (!(need > 0.0f) | !(q < need * need));
+        // 1 / (2 pi (1 - cos_max)), cos_max = sqrt(1 - r^2 / d^2):  1 / (1 - c) = (1 + c) d^2 / r^2, so the value is
+        // (d^2 + sqrt((d^2 - r^2) d^2)) / (2 pi r^2) -- one square root, no reciprocal; d^2 = |l|^2 + tc^2 for a unit
+        // direction.  An origin inside the sphere gives NaN like the reference's sqrt of a negative number.
+        const float d2 = __builtin_fmaf(tc, tc, len2(l));
+        pdf += seen ? (d2 + __builtin_amdgcn_sqrtf((d2 - r2) * d2)) * recf(R, 5) : 0.0f;
+    }
 }
-// hittable_list_hit (hittable_list.c:125-143) over the packed leaves.  `src` = leaf the ray starts on: a sphere left behind
-// has the roots {0, 2 tc} (rt_core.hpp sphere_leave_t), a rect or box face left behind is not tested again.
+// hittable_list_hit (hittable_list.c:125-143) over the record stream of the pack (rtc_tables.h SmallRec): one s_load_dwordx16 per
+// record by a wave-uniform cursor.  The records that run on the world ray are sorted by type, so each type is one counted loop with
+// one arm and the hit (t, leaf) stays in its registers -- a single loop with a type switch cost ten scalar instructions per record
+// for the dispatch and four moves to bring each arm's result back to the loop's registers.  A box alone behind a y-rotation is one
+// self-contained record among them; what is left -- general rotations, spaces with loose rects -- follows in a loop that carries its
+// current space and does look at the type.  Wrapper stacks are pre-collapsed affine maps.
 // `pdf` (out) = sum over the light-list entries that are leaves of this pack of their pdf for this ray (fused scenes, flatten.cpp
-// mark_small_lights; 0 otherwise): what small_light_pdf_sum would return for (ow, dw), taken from the tests that run here anyway.
+// mark_small_lights; 0 otherwise): what small_light_pdf_sum would return for (ow, dw), taken from the tests that run here anyway
+// (lights are matched to world-space leaves only).
 template <bool PDF>
 RT_DEV SmallHit small_closest_hit(const SmallScene &ss, f3 ow, f3 dw, float tmin, int src, float &pdf) {
     pdf = 0.0f;
     SmallHit h; h.t = 3.0e38f; h.leaf = -1;
     const f3 invw = rcp3(dw);
-    // The world-space group (xform 0 sorts first, flatten.cpp build_small_pack) runs on the world ray as it is; written as
-    // one loop with `o = ow; if (xform) o = ...` the compiler copies nine registers per group to have something to overwrite.
-    int gi = 0;
-    if (ss.n_groups > 0 && ss.groups[0].xform == 0) { small_group_hit<PDF>(ss, ss.groups[0], ow, dw, invw, tmin, src, h, pdf); gi = 1; }
-    for (; gi < ss.n_groups; ++gi) {
-        const SmallGroup g = ss.groups[gi];                      // wave-uniform
-        const SmallXform x = ss.xforms[g.xform];
-        f3 o, d, inv;
-        if (g.rot_y) {   // a rotation about y and a translation (every rotated object of the reference's scenes): y passes through
-            o = f3mk(x.m[0] * ow.x + x.m[2] * ow.z + x.b[0], ow.y + x.b[1], x.m[6] * ow.x + x.m[8] * ow.z + x.b[2]);
-            d = f3mk(x.m[0] * dw.x + x.m[2] * dw.z, dw.y, x.m[6] * dw.x + x.m[8] * dw.z);
-            inv = f3mk(__builtin_amdgcn_rcpf(d.x), invw.y, __builtin_amdgcn_rcpf(d.z));
-        } else { o = xform_point(x, ow); d = xform_dir(x, dw); inv = rcp3(d); }
-        float no_pdf = 0.0f;                                      // (lights are matched to world-space leaves only)
-        small_group_hit<false>(ss, g, o, d, inv, tmin, src, h, no_pdf);
+    const u32x16 *prog = reinterpret_cast<const u32x16 *>(ss.prog);
+    for (int k = 0; k < ss.n_box; ++k) { const u32x16 R = *prog++; small_box(R, ow, invw, tmin, src, h); }
+    for (int k = 0; k < ss.n_xbox; ++k) {   // a rotation about y and a translation (every rotated object of the reference's scenes): y passes through
+        const u32x16 R = *prog++;
+        const float m0 = recf(R, 9), m2 = recf(R, 10), m6 = recf(R, 11), m8 = recf(R, 12);
+        const f3 o = f3mk(m0 * ow.x + m2 * ow.z + recf(R, 13), ow.y + recf(R, 14), m6 * ow.x + m8 * ow.z + recf(R, 15));
+        const float dx = m0 * dw.x + m2 * dw.z, dz = m6 * dw.x + m8 * dw.z;
+        small_box(R, o, f3mk(__builtin_amdgcn_rcpf(dx), invw.y, __builtin_amdgcn_rcpf(dz)), tmin, src, h);
     }
-    if (ss.n_spheres > 0) {                                      // world space, closest-approach form (rt_core.hpp sphere_t<float>)
-        for (int s = 0; s < ss.n_spheres; ++s) {                 // |dw| = 1 (every ray of this kernel): the quadratic's a is 1
-            const SmallSphere sp = ss.spheres[s];
-            const int id = ss.n_rects + s;
-            const f3 oc = ow - f3mk(sp.c[0], sp.c[1], sp.c[2]);
-            const float tc = -dot(oc, dw);
-            const f3 l = oc + dw * tc;
-            const float q = sp.r2 - len2(l);
-            const float sq = __builtin_amdgcn_sqrtf(fmaxf(q, 0.0f));
-            const bool from = id == src;                         // leaving this sphere: roots are {0, 2 tc}
-            const float t0 = from ? 2.0f * tc : tc - sq, t1 = tc + sq;
-            const bool ok0 = (t0 >= tmin) & (t0 <= h.t), ok1 = (t1 >= tmin) & (t1 <= h.t) & !from;
-            const float t = ok0 ? t0 : t1;
-            const bool hit = (from | (q >= 0.0f)) & (ok0 | ok1);
-            h.t = hit ? t : h.t; h.leaf = hit ? id : h.leaf;
-            if (PDF && sp.pdf_k != 0.0f) {                           // wave-uniform: this sphere is a light-list entry (hittable.c:760-768)
-                const float need = 0.001f - tc;                      // the far root tc + sqrt(q) decides alone: small_light_pdf_one
-                const bool seen = !(q < 0.0f) & (!(need > 0.0f) | !(q < need * need));
-                // 1 / (2 pi (1 - cos_max)), cos_max = sqrt(1 - r^2 / d^2):  1 / (1 - c) = (1 + c) d^2 / r^2, so the value is
-                // (d^2 + sqrt((d^2 - r^2) d^2)) / (2 pi r^2) -- one square root, no reciprocal; d^2 = |l|^2 + tc^2 for a unit
-                // direction.  An origin inside the sphere gives NaN like the reference's sqrt of a negative number.
-                const float d2 = __builtin_fmaf(tc, tc, len2(l));
-                pdf += seen ? (d2 + __builtin_amdgcn_sqrtf((d2 - sp.r2) * d2)) * sp.pdf_k : 0.0f;
-            }
+    for (int k = 0; k < ss.n_xy; ++k) { const u32x16 R = *prog++; small_pair<PDF>(R, ow.z, invw.z, ow.x, dw.x, ow.y, dw.y, tmin, src, h, pdf); }
+    for (int k = 0; k < ss.n_xz; ++k) { const u32x16 R = *prog++; small_pair<PDF>(R, ow.y, invw.y, ow.x, dw.x, ow.z, dw.z, tmin, src, h, pdf); }
+    for (int k = 0; k < ss.n_yz; ++k) { const u32x16 R = *prog++; small_pair<PDF>(R, ow.x, invw.x, ow.y, dw.y, ow.z, dw.z, tmin, src, h, pdf); }
+    for (int k = 0; k < ss.n_sphere; ++k) { const u32x16 R = *prog++; small_sphere<PDF>(R, ow, dw, tmin, src, h, pdf); }
+    const u32x16 *const end = reinterpret_cast<const u32x16 *>(ss.prog) + ss.n_recs;
+    if (prog < end) {
+        f3 o = ow, d = dw, inv = invw;
+        float no_pdf = 0.0f;
+        for (; prog < end; ++prog) {
+            const u32x16 R = *prog;
+            const uint32_t type = R[0] & 0xffu;
+            if (type == RTC_SR_XFORM) {
+                if (R[0] & (1u << 8)) {
+                    o = f3mk(recf(R, 1) * ow.x + recf(R, 3) * ow.z + recf(R, 10), ow.y + recf(R, 11), recf(R, 7) * ow.x + recf(R, 9) * ow.z + recf(R, 12));
+                    d = f3mk(recf(R, 1) * dw.x + recf(R, 3) * dw.z, dw.y, recf(R, 7) * dw.x + recf(R, 9) * dw.z);
+                    inv = f3mk(__builtin_amdgcn_rcpf(d.x), invw.y, __builtin_amdgcn_rcpf(d.z));
+                } else {
+                    o = f3mk(recf(R, 1) * ow.x + recf(R, 2) * ow.y + recf(R, 3) * ow.z + recf(R, 10), recf(R, 4) * ow.x + recf(R, 5) * ow.y + recf(R, 6) * ow.z + recf(R, 11),
+                             recf(R, 7) * ow.x + recf(R, 8) * ow.y + recf(R, 9) * ow.z + recf(R, 12));
+                    d = f3mk(recf(R, 1) * dw.x + recf(R, 2) * dw.y + recf(R, 3) * dw.z, recf(R, 4) * dw.x + recf(R, 5) * dw.y + recf(R, 6) * dw.z, recf(R, 7) * dw.x + recf(R, 8) * dw.y + recf(R, 9) * dw.z);
+                    inv = rcp3(d);
+                }
+            } else if (type == RTC_SR_BOX) small_box(R, o, inv, tmin, src, h);
+            else small_pair_any<false>(R, o, d, inv, tmin, src, h, no_pdf);
         }
     }
     return h;

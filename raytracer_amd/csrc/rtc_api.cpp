@@ -182,7 +182,7 @@ struct rtc_scene {
     hipEvent_t wf_done = nullptr;              // end of the last wavefront render's final accumulate: the pool is shared by all streams
     hipStream_t wf_stream[4] = {nullptr, nullptr, nullptr, nullptr};   // streams of the parts a wavefront render is split into (part 0 runs on the caller's)
     hipEvent_t wf_fork = nullptr, wf_part_done[4] = {nullptr, nullptr, nullptr, nullptr};
-    DevBuf small_pairs, small_groups, small_spheres, small_shade, small_xforms, small_boxes;
+    DevBuf small_prog, small_shade;            // the small-scene pack as the kernel reads it: record stream + shading records
     SmallScene small{};   // n_leaves == 0: not eligible
     std::map<void *, StreamState> streams;
     std::mutex mu;
@@ -214,6 +214,76 @@ const char *rtc_device_name(void) {
     return name;
 }
 
+// The small-scene pack as the record stream k_pathtrace_small reads (rtc_tables.h SmallRec): world-space records first (the world
+// group's box and pairs, the spheres, and every y-rotated space that holds one box and nothing else, folded into one self-contained
+// record), then the other object spaces, each led by its transform.  Boxes and rects go to centre / half-extent form, the half extent
+// rounded outward.
+static std::vector<SmallRec> build_small_program(const FlatScene &fs, int counts[6]) {
+    auto fbits = [](float f) { uint32_t u; std::memcpy(&u, &f, sizeof u); return u; };
+    auto centre = [](float lo, float hi) { return (float)(0.5 * ((double)lo + (double)hi)); };
+    auto half = [](float lo, float hi) { const float h = (float)(0.5 * ((double)hi - (double)lo)); return (double)h < 0.5 * ((double)hi - (double)lo) ? std::nextafter(h, HUGE_VALF) : h; };
+    std::vector<SmallRec> boxes, xboxes, pairs[3], spheres, general;
+    auto box_rec = [&](const SmallBox &B, uint32_t type) {
+        SmallRec r{}; r.w[0] = type;
+        auto id = [&](uint32_t ids, int e) { return (ids >> (8 * e)) & 0xffu; };
+        r.w[1] = id(B.ids_lo, 0) | id(B.ids_hi, 0) << 8 | id(B.ids_lo, 1) << 16 | id(B.ids_hi, 1) << 24;
+        r.w[2] = id(B.ids_lo, 2) | id(B.ids_hi, 2) << 8;
+        for (int e = 0; e < 3; e++) { r.w[3 + e] = fbits(centre(B.lo[e], B.hi[e])); r.w[6 + e] = fbits(half(B.lo[e], B.hi[e])); }
+        return r;
+    };
+    auto pair_recs = [&](const SmallGroup &g, std::vector<SmallRec> *by_axis, std::vector<SmallRec> *all) {
+        const int first[3] = {g.first, g.first + g.n_xy, g.first + g.n_xy + g.n_xz}, count[3] = {g.n_xy, g.n_xz, g.n_yz};
+        for (int axis = 0; axis < 3; axis++)                            // RTC_AXIS_XY, _XZ, _YZ
+            for (int p = first[axis]; p < first[axis] + count[axis]; p++) {
+                const SmallPair &P = fs.small_pairs[(size_t)p];
+                int id0, id1; std::memcpy(&id0, &P.f[10], sizeof id0); std::memcpy(&id1, &P.f[11], sizeof id1);
+                SmallRec r{};
+                r.w[0] = RTC_SR_PAIR | (uint32_t)axis << 8 | (id1 >= 0 ? 1u << 10 : 0u) | (P.f[12] != 0.0f ? 1u << 11 : 0u) | (id1 >= 0 && P.f[13] != 0.0f ? 1u << 12 : 0u)
+                       | ((uint32_t)id0 & 0xffu) << 16 | ((uint32_t)(id1 >= 0 ? id1 : 0xff) & 0xffu) << 24;
+                r.w[1] = fbits(P.f[0]); r.w[2] = fbits(P.f[1]);
+                for (int k = 0; k < 2; k++) {
+                    if (k == 1 && id1 < 0) break;
+                    const float *b = &P.f[2 + 4 * k];                   // lo_a lo_b hi_a hi_b
+                    r.w[3 + 4 * k] = fbits(centre(b[0], b[2])); r.w[4 + 4 * k] = fbits(centre(b[1], b[3]));
+                    r.w[5 + 4 * k] = fbits(half(b[0], b[2])); r.w[6 + 4 * k] = fbits(half(b[1], b[3]));
+                    r.w[11 + k] = fbits(P.f[12 + k]);
+                }
+                (by_axis ? by_axis[axis] : *all).push_back(r);
+            }
+    };
+    for (const SmallGroup &g : fs.small_groups) {
+        const SmallXform &X = fs.small_xforms[(size_t)g.xform];
+        const int n_pairs = g.n_xy + g.n_xz + g.n_yz;
+        if (g.xform == 0) {                                             // the world's own space (identity)
+            if (g.box >= 0) boxes.push_back(box_rec(fs.small_boxes[(size_t)g.box], RTC_SR_BOX));
+            pair_recs(g, pairs, nullptr);
+        } else if (g.rot_y && g.box >= 0 && n_pairs == 0) {
+            SmallRec r = box_rec(fs.small_boxes[(size_t)g.box], RTC_SR_XBOX_Y);
+            r.w[9] = fbits(X.m[0]); r.w[10] = fbits(X.m[2]); r.w[11] = fbits(X.m[6]); r.w[12] = fbits(X.m[8]);
+            for (int k = 0; k < 3; k++) r.w[13 + k] = fbits(X.b[k]);
+            xboxes.push_back(r);
+        } else {
+            SmallRec r{}; r.w[0] = RTC_SR_XFORM | (g.rot_y ? 1u << 8 : 0u);
+            for (int k = 0; k < 9; k++) r.w[1 + k] = fbits(X.m[k]);
+            for (int k = 0; k < 3; k++) r.w[10 + k] = fbits(X.b[k]);
+            general.push_back(r);
+            if (g.box >= 0) general.push_back(box_rec(fs.small_boxes[(size_t)g.box], RTC_SR_BOX));
+            pair_recs(g, nullptr, &general);
+        }
+    }
+    for (size_t i = 0; i < fs.small_spheres.size(); i++) {
+        const SmallSphere &sp = fs.small_spheres[i];
+        SmallRec r{}; r.w[0] = RTC_SR_SPHERE | ((uint32_t)(fs.small_n_rects + (int)i) & 0xffu) << 8 | (sp.pdf_k != 0.0f ? 1u << 16 : 0u);
+        for (int k = 0; k < 3; k++) r.w[1 + k] = fbits(sp.c[k]);
+        r.w[4] = fbits(sp.r2); r.w[5] = fbits(sp.pdf_k);
+        spheres.push_back(r);
+    }
+    std::vector<SmallRec> prog;
+    const std::vector<SmallRec> *parts[7] = {&boxes, &xboxes, &pairs[0], &pairs[1], &pairs[2], &spheres, &general};
+    for (int k = 0; k < 7; k++) { if (k < 6) counts[k] = (int)parts[k]->size(); prog.insert(prog.end(), parts[k]->begin(), parts[k]->end()); }
+    return prog;
+}
+
 // device tables of a flattened scene on the current device (rtc_scene_build and rtc_scene_load)
 static rtc_scene *upload_scene(rtc_scene *s, const char *who) {
     if (hipGetDevice(&s->device) != hipSuccess) return fail_scene(s, std::string(who) + ": no current HIP device");
@@ -222,19 +292,14 @@ static rtc_scene *upload_scene(rtc_scene *s, const char *who) {
     if (e == hipSuccess) e = s->ray_counter.upload(zero.data(), zero.size());
     if (e == hipSuccess && s->flat.small_ok) {
         const FlatScene &fs = s->flat;
-        e = s->small_pairs.upload(fs.small_pairs.data(), fs.small_pairs.size() * sizeof(SmallPair));
-        if (e == hipSuccess) e = s->small_groups.upload(fs.small_groups.data(), fs.small_groups.size() * sizeof(SmallGroup));
-        if (e == hipSuccess) e = s->small_spheres.upload(fs.small_spheres.data(), fs.small_spheres.size() * sizeof(SmallSphere));
+        int counts[6];
+        const std::vector<SmallRec> prog = build_small_program(fs, counts);
+        e = s->small_prog.upload(prog.data(), prog.size() * sizeof(SmallRec));
         if (e == hipSuccess) e = s->small_shade.upload(fs.small_shade.data(), fs.small_shade.size() * sizeof(SmallShade));
-        if (e == hipSuccess) e = s->small_xforms.upload(fs.small_xforms.data(), fs.small_xforms.size() * sizeof(SmallXform));
-        if (e == hipSuccess) e = s->small_boxes.upload(fs.small_boxes.data(), fs.small_boxes.size() * sizeof(SmallBox));
         SmallScene &m = s->small;
-        m.boxes = (const SmallBox *)s->small_boxes.p;
-        m.pairs = (const SmallPair *)s->small_pairs.p; m.groups = (const SmallGroup *)s->small_groups.p;
-        m.spheres = (const SmallSphere *)s->small_spheres.p; m.shade = (const SmallShade *)s->small_shade.p;
-        m.xforms = (const SmallXform *)s->small_xforms.p;
-        m.n_rects = fs.small_n_rects; m.n_pairs = (int)fs.small_pairs.size(); m.n_groups = (int)fs.small_groups.size(); m.n_spheres = (int)fs.small_spheres.size();
-        m.n_xforms = (int)fs.small_xforms.size(); m.n_leaves = (int)fs.small_shade.size(); m.any_fuzz = fs.small_any_fuzz;
+        m.prog = (const SmallRec *)s->small_prog.p; m.shade = (const SmallShade *)s->small_shade.p;
+        m.n_box = counts[0]; m.n_xbox = counts[1]; m.n_xy = counts[2]; m.n_xz = counts[3]; m.n_yz = counts[4]; m.n_sphere = counts[5]; m.n_recs = (int)prog.size();
+        m.n_leaves = (int)fs.small_shade.size(); m.any_fuzz = fs.small_any_fuzz;
         m.fused_lights = fs.small_fused;
     }
     if (e != hipSuccess) return fail_scene(s, std::string(who) + ": upload failed: " + hipGetErrorString(e));

@@ -131,12 +131,30 @@ struct alignas(32) SmallBox { float lo[3], hi[3]; uint32_t ids_lo, ids_hi; };
 struct alignas(32) SmallSphere { float c[3]; float r2; float pdf_k; float pad[3]; };
 struct alignas(16) SmallShade { uint32_t meta; float rgb[3]; float g[4]; float param; float pad[3]; };   // param: fuzz / ir; glass: pad[0] = 1 / ir, pad[1] = Schlick r0
 struct SmallXform { float m[9]; float b[3]; };
+// What the small-scene kernel reads: the pack above as ONE stream of 64-byte records (built at upload time, rtc_api.cpp
+// build_small_program), each fetched with one s_load_dwordx16 by a wave-uniform cursor -- no group -> box -> pair indirection
+// (every hop was a dependent scalar load the wave waited for), no loops over empty runs.  On gfx950 a scalar instruction takes an
+// issue slot like a vector one (tools/ubench/valu_issue: "mix" rows), so the scalar side of the intersection is part of its cost.
+//   w[0] = head: bits 0-7 the record type, then per type:
+//   RTC_SR_BOX    : slab test of a SmallBox in the current object space.  w[1] = face ids lo_x | hi_x << 8 | lo_y << 16 | hi_y << 24,
+//                   w[2] = lo_z | hi_z << 8 (0xff: no such face), f[3..5] = centre, f[6..8] = half extent (rounded outward)
+//   RTC_SR_XBOX_Y : the same box behind a y-rotation + translation that holds nothing else (hittable_box under rotate_y + translate):
+//                   f[9..12] = m0 m2 m6 m8, f[13..15] = b.  Self-contained: it does not change the current space
+//   RTC_SR_PAIR   : two rects of one axis run.  head bits 8-9 axis (RTC_AXIS_*), 10: second rect present, 11 / 12: rect 0 / 1 is a
+//                   light-list entry, 16-23 / 24-31 their leaf ids; f[1], f[2] = plane k; f[3..6] / f[7..10] = centre a, centre b, half a,
+//                   half b; f[11], f[12] = 1 / area of a light-list entry
+//   RTC_SR_SPHERE : head bits 8-15 leaf id, 16: light-list entry; f[1..3] centre, f[4] = r^2, f[5] = count / (2 pi r^2)   (world space)
+//   RTC_SR_XFORM  : the records that follow live in this object space.  head bit 8: y-rotation; f[1..9] = M, f[10..12] = b
+// Order: the records that run on the world ray as it is come first, SORTED BY TYPE -- boxes, self-contained XBOX_Y, pairs by axis, spheres
+// (SmallScene::n_box ... n_sphere) -- so that the kernel runs one counted loop per type and no type dispatch; then the general object
+// spaces, each led by its RTC_SR_XFORM (the only part that looks at a record's type).
+enum { RTC_SR_BOX = 1, RTC_SR_XBOX_Y = 2, RTC_SR_PAIR = 3, RTC_SR_SPHERE = 4, RTC_SR_XFORM = 5 };
+struct alignas(64) SmallRec { uint32_t w[16]; };
 struct SmallScene {
-    const SmallPair *pairs; const SmallGroup *groups; const SmallSphere *spheres; const SmallShade *shade; const SmallXform *xforms;
-    const SmallBox *boxes;
-    int n_pairs, n_groups, n_spheres, n_xforms;
-    int n_rects;                                   // leaf id of sphere s = n_rects + s
-    int n_leaves;                                  // n_rects + n_spheres
+    const SmallRec *prog; const SmallShade *shade;
+    int n_box, n_xbox, n_xy, n_xz, n_yz, n_sphere; // world-ray records by type, in this order
+    int n_recs;                                    // all records (the general object spaces follow the world-ray ones)
+    int n_leaves;                                  // shading records (rects first, then spheres)
     int any_fuzz;                                  // some metal has fuzz > 0
     int fused_lights;                              // every light's pdf comes out of the intersection of the next ray (flatten.cpp mark_small_lights)
 };

@@ -86,6 +86,24 @@ constexpr int ITERS = 16384;
 #define T_CND_IMOV(D, A, B) "v_cndmask_b32 v" #D ", v" #D ", v" #B ", vcc\n v_mov_b32 v20, v" #A "\n"
 #define T_CND_CMPS(D, A, B) "v_cndmask_b32 v" #D ", v" #D ", v" #B ", vcc\n v_cmp_lt_f32 s[20:21], v" #D ", v" #A "\n"
 #define T_CND2_MUL(D, A, B) "v_cndmask_b32 v" #D ", v" #D ", v" #B ", vcc\n v_cndmask_b32 v20, v20, v" #A ", vcc\n v_mul_f32 v" #D ", v" #D ", v" #A "\n"
+#define T_MUL_SALU(D, A, B) "v_mul_f32 v" #D ", v" #D ", v" #A "\n s_add_i32 s22, s22, 1\n"
+#define T_MUL_SALU2(D, A, B) "v_mul_f32 v" #D ", v" #D ", v" #A "\n s_add_i32 s22, s22, 1\n s_and_b64 s[20:21], s[20:21], exec\n"
+#define T_MUL4_SALU(D, A, B) "v_mul_f32 v" #D ", v" #D ", v" #A "\n s_add_i32 s22, s22, 1\n v_max_f32 v" #D ", v" #D ", v" #B "\n"
+#define M_MUL(D, A) "v_mul_f32 v" #D ", v" #D ", v" #A "\n"
+#define M_MAX(D, B) "v_max_f32 v" #D ", v" #D ", v" #B "\n"
+#define T_M1(D, A, B) M_MUL(D, A) M_MAX(D, B)
+#define T_M2(D, A, B) M_MUL(D, A) M_MUL(D, B) M_MAX(D, B)
+#define T_M3(D, A, B) M_MUL(D, A) M_MAX(D, A) M_MAX(D, B)
+#define T_M4(D, A, B) M_MUL(D, A) "v_mul_f32 v" #D ", %0, v" #D "\n"
+#define T_M5(D, A, B) M_MUL(D, A) "v_cmp_lt_f32 vcc, v" #D ", v" #B "\n"
+#define T_M6(D, A, B) M_MUL(D, A) M_MUL(D, B) M_MUL(D, A) "v_rcp_f32 v" #D ", v" #D "\n"
+#define T_M7(D, A, B) M_MUL(D, A) M_MUL(D, B) "s_add_i32 s22, s22, 1\n"
+#define T_M8(D, A, B) M_MUL(D, A) M_MUL(D, B) M_MUL(D, A) M_MUL(D, B) "s_add_i32 s22, s22, 1\n"
+#define T_M9(D, A, B) M_MAX(D, A) "s_add_i32 s22, s22, 1\n"
+#define T_M10(D, A, B) M_MUL(D, A) "s_mov_b32 s22, s23\n"
+#define T_M11(D, A, B) M_MAX(D, A) "s_mov_b32 s22, s23\n s_mov_b32 s24, s23\n"
+#define T_M12(D, A, B) M_MUL(D, A) "s_mov_b32 s22, s23\n s_mov_b32 s24, s23\n"
+#define CASE_M(N, T) if (OP == N) { asm volatile(REP8(GROUP(T)) :: "s"(seed) : ACC8, "vcc", "scc", "s22", "s23", "s24"); }
 #define CASE_V(N, T) if (OP == N) { asm volatile(REP8(GROUP(T)) ::: ACC8, "vcc"); }
 #define CASE_S(N, T) if (OP == N) { asm volatile(REP8(GROUP(T)) :: "s"(seed) : ACC8, "vcc"); }
 #define CASE_P(N, T) if (OP == N) { asm volatile(REP8(GROUP4(T)) ::: ACC8, "vcc"); }
@@ -143,6 +161,11 @@ template <int OP> __global__ void __launch_bounds__(256) k(unsigned long long *c
         if (OP == 91) { asm volatile(REP8(GROUP(T_CND_IMOV)) ::: ACC8, "v20"); }
         if (OP == 92) { asm volatile(REP8(GROUP(T_CND_CMPS)) ::: ACC8, "s20", "s21"); }
         if (OP == 93) { asm volatile(REP8(GROUP(T_CND2_MUL)) ::: ACC8, "v20"); }
+        if (OP == 94) { asm volatile(REP8(GROUP(T_MUL_SALU)) ::: ACC8, "s22", "scc"); }
+        if (OP == 95) { asm volatile(REP8(GROUP(T_MUL_SALU2)) ::: ACC8, "s20", "s21", "s22", "scc"); }
+        if (OP == 96) { asm volatile(REP8(GROUP(T_MUL4_SALU)) ::: ACC8, "s22", "scc"); }
+        CASE_M(100, T_M1) CASE_M(101, T_M2) CASE_M(102, T_M3) CASE_M(103, T_M4) CASE_M(104, T_M5) CASE_M(105, T_M6) CASE_M(106, T_M7) CASE_M(107, T_M8)
+        CASE_M(108, T_M9) CASE_M(109, T_M10) CASE_M(110, T_M11) CASE_M(111, T_M12)
         CASE_V(73, T_LDEXP) CASE_V(74, T_FRACT) CASE_V(75, T_FLOOR)
     }
     const unsigned long long t1 = __builtin_readcyclecounter();
@@ -217,6 +240,11 @@ int main() {
     run<88>("v_cndmask e32 (vcc) + e64 (s[20:21]) pairs (per instr)", 128); run<89>("v_cndmask (vcc) + s_mov_b32 (per cndmask)", 64);
     run<90>("v_cndmask (vcc) + independent v_mul (per instr)", 128); run<91>("v_cndmask (vcc) + independent v_mov (per instr)", 128);
     run<92>("v_cndmask (vcc) + v_cmp -> s[20:21] (per instr)", 128); run<93>("2 v_cndmask (vcc) + v_mul (per instr)", 192);
+    run<94>("v_mul_f32 + 1 SALU each (per v_mul)", 64); run<95>("v_mul_f32 + 2 SALU each (per v_mul)", 64); run<96>("v_mul + s_add + v_max (per VALU instr)", 128);
+    printf("-- mixes: cycles per GROUP of the instructions named --\n");
+    run<100>("mix: v_mul + v_max", 64); run<101>("mix: 2 v_mul + v_max", 64); run<102>("mix: v_mul + 2 v_max", 64); run<103>("mix: v_mul + v_mul(SGPR)", 64);
+    run<104>("mix: v_mul + v_cmp", 64); run<105>("mix: 3 v_mul + v_rcp", 64); run<106>("mix: 2 v_mul + s_add", 64); run<107>("mix: 4 v_mul + s_add", 64);
+    run<108>("mix: v_max + s_add", 64); run<109>("mix: v_mul + s_mov", 64); run<110>("mix: v_max + 2 s_mov", 64); run<111>("mix: v_mul + 2 s_mov", 64);
     run<30>("v_add_u32", 64); run<31>("v_lshlrev_b32", 64); run<32>("v_lshrrev_b32", 64); run<33>("v_and_b32", 64); run<43>("v_bfe_u32", 64); run<68>("v_bfi_b32", 64); run<44>("v_perm_b32", 64);
     run<45>("v_and_or_b32", 64); run<46>("v_lshl_add_u32", 64); run<47>("v_add3_u32", 64);
     run<34>("v_mul_lo_u32", 64); run<35>("v_mul_hi_u32", 64); run<65>("v_mul_u32_u24", 64); run<66>("v_mad_u32_u24", 64); run<36>("v_mad_u64_u32 (32 per iteration)", 32);

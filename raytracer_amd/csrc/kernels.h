@@ -85,4 +85,4 @@ enum { RTC_KAT_PHILOX = 0, RTC_KAT_LIGHT_PDF = 1, RTC_KAT_LIGHT_PDF_SMALL = 2, R
 __host__ __device__ inline int rtc_kat_in_stride(int what) { const int s[RTC_KAT_COUNT] = {5, 6, 6, 6, 2, 7, 6, 6, 9, 9}; return what >= 0 && what < RTC_KAT_COUNT ? s[what] : 0; }
 __host__ __device__ inline int rtc_kat_out_stride(int what) { const int s[RTC_KAT_COUNT] = {4, 1, 1, 1, 1, 3, 3, 3, 3, 3}; return what >= 0 && what < RTC_KAT_COUNT ? s[what] : 0; }
 hipError_t launch_kat(const SceneT<float> &sc, int what, const double *in, unsigned n, double *out, hipStream_t stream);
-hipError_t launch_small_kat(const SceneT<float> &sc, int what, const double *in, unsigned n, double *out, hipStream_t stream);
+hipError_t launch_small_kat(const SceneT<float> &sc, const SmallScene &ss, int what, const double *in, unsigned n, double *out, hipStream_t stream);

@@ -232,19 +232,25 @@ RT_DEV void basis_around(f3 w, f3 &u, f3 &v) {
     u = f3mk(1.0f + sign * w.x * w.x * a, sign * b, -sign * w.x);
     v = f3mk(b, sign + w.y * w.y * a, -w.y);
 }
-RT_DEV f3 small_light_sample(const SceneT<float> &sc, int pick, f3 o, float r1, float r2) {
+// hittable_list_random (hittable_list.c:174-180) + hittable_random (hittable.c:821-848) over the light records of the pack (rtc_tables.h):
+// a wave-uniform loop with one s_load_dwordx16 per light, the picked light a per-lane mask.  (Reading LightT -- kind, axis and eight
+// reals chosen by axis -- cost thirty scalar instructions and a dozen moves per rect light: every `axis ==` became a scalar select.)
+RT_DEV f3 small_light_sample(const SmallScene &ss, int pick, f3 o, float r1, float r2) {
     f3 dir = f3mk(1, 0, 0);                                                                // hittable.c:861-863
-    for (int i = 0; i < sc.n_lights; ++i) {                                               // uniform loop, per-lane select
-        const LightT<float> &l = sc.lights[i];
+    const u32x16 *const lights = reinterpret_cast<const u32x16 *>(ss.lights);
+    for (int i = 0; i < ss.n_lights; ++i) {
+        const u32x16 R = lights[i];
         if (pick != i) continue;
-        if (l.kind == RTC_LIGHT_RECT) dir = light_random_one(l, o, r1, r2);               // hittable.c:838-848
-        else if (l.kind == RTC_LIGHT_SPHERE) {                                            // hittable.c:821-835, cone towards the sphere
-            const f3 axis = f3mk(l.d[0], l.d[1], l.d[2]) - o;
+        if (R[0] == RTC_LIGHT_RECT) {                                                      // hittable.c:838-848: a uniform point of the rect
+            dir = f3mk(__builtin_fmaf(recf(R, 7), r2, __builtin_fmaf(recf(R, 4), r1, recf(R, 1) - o.x)), __builtin_fmaf(recf(R, 8), r2, __builtin_fmaf(recf(R, 5), r1, recf(R, 2) - o.y)),
+                       __builtin_fmaf(recf(R, 9), r2, __builtin_fmaf(recf(R, 6), r1, recf(R, 3) - o.z)));
+        } else if (R[0] == RTC_LIGHT_SPHERE) {                                             // hittable.c:821-835, cone towards the sphere
+            const f3 axis = f3mk(recf(R, 1), recf(R, 2), recf(R, 3)) - o;
             const float d2 = len2(axis);
             const float inv_d = __builtin_amdgcn_rsqf(d2);
             const f3 w = axis * inv_d;
             f3 u, v; basis_around(w, u, v);
-            const float z = 1.0f + r2 * (__builtin_amdgcn_sqrtf(fmaxf(0.0f, 1.0f - l.d[4] * (inv_d * inv_d))) - 1.0f);
+            const float z = 1.0f + r2 * (__builtin_amdgcn_sqrtf(fmaxf(0.0f, 1.0f - recf(R, 4) * (inv_d * inv_d))) - 1.0f);
             const float s = __builtin_amdgcn_sqrtf(fmaxf(0.0f, 1.0f - z * z));
             dir = u * (cos2pi(r1) * s) + (v * (sin2pi(r1) * s) + w * z);
         }
@@ -433,10 +439,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RT_SMA
                     T = T * col;
                 } else {                                                    // 03: ray.c:66-83, mixture of light-list and cosine pdfs
                     const float w = P.light_weight;
-                    if (sc.n_lights > 0 && xi.x < w) {                       // pdf.c:175-181
-                        int pick = (int)((float)sc.n_lights * xi.y);         // random_int(0, n-1), utils.h:26
-                        pick = pick < sc.n_lights ? pick : sc.n_lights - 1;
-                        nd = small_light_sample(sc, pick, p, xi.z, xi.w);
+                    if (ss.n_lights > 0 && xi.x < w) {                       // pdf.c:175-181
+                        int pick = (int)((float)ss.n_lights * xi.y);         // random_int(0, n-1), utils.h:26
+                        pick = pick < ss.n_lights ? pick : ss.n_lights - 1;
+                        nd = small_light_sample(ss, pick, p, xi.z, xi.w);
                     } else {                                                 // cosine law about n (vec3.c:97-107 + onb.c:25-30)
                         nd = n + uniform_sphere(xi.z, xi.w);
                         if (len2(nd) < 1e-12f) nd = n;
@@ -507,7 +513,7 @@ __global__ void __launch_bounds__(1024) k_tile_order(const int *__restrict__ cos
 
 // Known-answer probe of this file's own shading functions (they differ from rt_shade.hpp's: unit directions, folded hit
 // tests, basis-free samplers), on supplied inputs; kernels_probe.hip has the general ones.
-__global__ void __launch_bounds__(256) k_small_kat(SceneT<float> sc, int what, const double *__restrict__ in, unsigned n, double *__restrict__ out) {
+__global__ void __launch_bounds__(256) k_small_kat(SceneT<float> sc, SmallScene ss, int what, const double *__restrict__ in, unsigned n, double *__restrict__ out) {
     const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const int si = rtc_kat_in_stride(what), so = rtc_kat_out_stride(what);
@@ -517,7 +523,7 @@ __global__ void __launch_bounds__(256) k_small_kat(SceneT<float> sc, int what, c
     if (what == RTC_KAT_LIGHT_PDF_SMALL) {            // the list pdf as the bounce loop computes it: sum over the lights for a UNIT direction, / n
         o[0] = sc.n_lights > 0 ? small_light_pdf_sum(sc, v3at(0), normalize(v3at(3))) / (float)sc.n_lights : 0.0f;
     } else if (what == RTC_KAT_LIGHT_SAMPLE_SMALL) {
-        const f3 d = small_light_sample(sc, (int)a[3], v3at(0), (float)a[4], (float)a[5]);
+        const f3 d = small_light_sample(ss, (int)a[3], v3at(0), (float)a[4], (float)a[5]);
         o[0] = d.x; o[1] = d.y; o[2] = d.z;
     } else if (what == RTC_KAT_DIELECTRIC_SMALL) {
         const float ir = (float)a[7], rr = (1.0f - ir) / (1.0f + ir);
@@ -528,9 +534,9 @@ __global__ void __launch_bounds__(256) k_small_kat(SceneT<float> sc, int what, c
 
 }  // namespace
 
-hipError_t launch_small_kat(const SceneT<float> &sc, int what, const double *in, unsigned n, double *out, hipStream_t stream) {
+hipError_t launch_small_kat(const SceneT<float> &sc, const SmallScene &ss, int what, const double *in, unsigned n, double *out, hipStream_t stream) {
     if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_small_kat, dim3((n + 255) / 256), dim3(256), 0, stream, sc, what, in, n, out);
+    hipLaunchKernelGGL(k_small_kat, dim3((n + 255) / 256), dim3(256), 0, stream, sc, ss, what, in, n, out);
     return hipGetLastError();
 }
 

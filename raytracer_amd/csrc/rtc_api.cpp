@@ -182,7 +182,7 @@ struct rtc_scene {
     hipEvent_t wf_done = nullptr;              // end of the last wavefront render's final accumulate: the pool is shared by all streams
     hipStream_t wf_stream[4] = {nullptr, nullptr, nullptr, nullptr};   // streams of the parts a wavefront render is split into (part 0 runs on the caller's)
     hipEvent_t wf_fork = nullptr, wf_part_done[4] = {nullptr, nullptr, nullptr, nullptr};
-    DevBuf small_prog, small_shade;            // the small-scene pack as the kernel reads it: record stream + shading records
+    DevBuf small_prog, small_shade, small_lights;            // the small-scene pack as the kernel reads it: record stream + shading records
     SmallScene small{};   // n_leaves == 0: not eligible
     std::map<void *, StreamState> streams;
     std::mutex mu;
@@ -284,12 +284,39 @@ static std::vector<SmallRec> build_small_program(const FlatScene &fs, int counts
     return prog;
 }
 
+// the light list as the small kernel samples it (rtc_tables.h): same (r1, r2) -> point map as rt_shade.hpp light_random_one
+static std::vector<SmallRec> build_small_lights(const FlatScene &fs) {
+    auto fbits = [](float f) { uint32_t u; std::memcpy(&u, &f, sizeof u); return u; };
+    std::vector<SmallRec> out;
+    for (const LightT<double> &l : fs.lights) {
+        SmallRec r{}; r.w[0] = (uint32_t)l.kind;
+        if (l.kind == RTC_LIGHT_RECT) {
+            // in-plane axes a, b and the normal axis n as x / y / z indices: XY -> (0, 1, 2), XZ -> (0, 2, 1), YZ -> (1, 2, 0)
+            const int ia = l.axis == RTC_AXIS_YZ ? 1 : 0, ib = l.axis == RTC_AXIS_XY ? 1 : 2, in = l.axis == RTC_AXIS_XY ? 2 : (l.axis == RTC_AXIS_XZ ? 1 : 0);
+            const float a0 = (float)l.d[2 * ia], a1 = (float)l.d[2 * ia + 1], b0 = (float)l.d[2 * ib], b1 = (float)l.d[2 * ib + 1];
+            float corner[3] = {0, 0, 0}, ea[3] = {0, 0, 0}, eb[3] = {0, 0, 0};
+            corner[ia] = a0; corner[ib] = b0; corner[in] = (float)l.d[6]; ea[ia] = a1 - a0; eb[ib] = b1 - b0;
+            for (int k = 0; k < 3; k++) { r.w[1 + k] = fbits(corner[k]); r.w[4 + k] = fbits(ea[k]); r.w[7 + k] = fbits(eb[k]); }
+        } else if (l.kind == RTC_LIGHT_SPHERE) {
+            for (int k = 0; k < 3; k++) r.w[1 + k] = fbits((float)l.d[k]);
+            r.w[4] = fbits((float)l.d[4]);
+        }
+        out.push_back(r);
+    }
+    return out;
+}
+
 // device tables of a flattened scene on the current device (rtc_scene_build and rtc_scene_load)
 static rtc_scene *upload_scene(rtc_scene *s, const char *who) {
     if (hipGetDevice(&s->device) != hipSuccess) return fail_scene(s, std::string(who) + ": no current HIP device");
     hipError_t e = upload_tables<float>(s->flat, s->f32, false);
     std::vector<unsigned char> zero(4 * (wf_stats_bytes() + 64), 0);   // per part of a wavefront render: striped statistics, 16 control words (kernels.h WF_*)
     if (e == hipSuccess) e = s->ray_counter.upload(zero.data(), zero.size());
+    if (e == hipSuccess) {
+        const std::vector<SmallRec> lights = build_small_lights(s->flat);
+        e = s->small_lights.upload(lights.data(), lights.size() * sizeof(SmallRec));
+        s->small.lights = (const SmallRec *)s->small_lights.p; s->small.n_lights = (int)lights.size();
+    }
     if (e == hipSuccess && s->flat.small_ok) {
         const FlatScene &fs = s->flat;
         int counts[6];
@@ -823,7 +850,7 @@ int rtc_kat(const rtc_scene *scene_c, int what, const double *in, size_t n, doub
     DevBuf d_in, d_out;
     HIP_TRY(d_in.upload(in, n * (size_t)rtc_kat_in_stride(what) * sizeof(double)));
     HIP_TRY(hipMalloc(&d_out.p, n * (size_t)rtc_kat_out_stride(what) * sizeof(double)));
-    if (small) HIP_TRY(launch_small_kat(s->f32.view, what, (const double *)d_in.p, (unsigned)n, (double *)d_out.p, nullptr));
+    if (small) HIP_TRY(launch_small_kat(s->f32.view, s->small, what, (const double *)d_in.p, (unsigned)n, (double *)d_out.p, nullptr));
     else HIP_TRY(launch_kat(s->f32.view, what, (const double *)d_in.p, (unsigned)n, (double *)d_out.p, nullptr));
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(out, d_out.p, n * (size_t)rtc_kat_out_stride(what) * sizeof(double), hipMemcpyDeviceToHost));

@@ -150,8 +150,13 @@ struct SmallXform { float m[9]; float b[3]; };
 // spaces, each led by its RTC_SR_XFORM (the only part that looks at a record's type).
 enum { RTC_SR_BOX = 1, RTC_SR_XBOX_Y = 2, RTC_SR_PAIR = 3, RTC_SR_SPHERE = 4, RTC_SR_XFORM = 5 };
 struct alignas(64) SmallRec { uint32_t w[16]; };
+// A light-list entry as the small kernel samples it (hittable.c:821-848), one record per entry of `lights`:
+//   w[0] = RTC_LIGHT_RECT  : f[1..3] = the corner (a0, b0) of the rect as a point, f[4..6] / f[7..9] = its two edge vectors:
+//                            point(r1, r2) = corner + r1 * edge_a + r2 * edge_b -- no axis selects in the kernel
+//   w[0] = RTC_LIGHT_SPHERE: f[1..3] = centre, f[4] = r^2
 struct SmallScene {
     const SmallRec *prog; const SmallShade *shade;
+    const SmallRec *lights; int n_lights;          // sampling records of the light list (all scenes, also those that are not small)
     int n_box, n_xbox, n_xy, n_xz, n_yz, n_sphere; // world-ray records by type, in this order
     int n_recs;                                    // all records (the general object spaces follow the world-ray ones)
     int n_leaves;                                  // shading records (rects first, then spheres)

@@ -367,7 +367,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RT_SMA
     for (;;) {
         if (P.max_depth <= 0) break;                                       // ray.c:52
         const bool starving = !alive && n_buf == 0;
-        if (q_next < n_paths && __builtin_amdgcn_ballot_w64(starving) != 0) {
+        if (q_next < n_paths && __builtin_amdgcn_ballot_w64(starving) != 0) {   // (waiting until 4 or 8 lanes starve: no gain, 0 to +2 %)
             int q;
             if (hand_out(n_buf == 0, q)) { primary(q, b0o, b0d); b0q = q; n_buf = 1; }
             if (hand_out(n_buf == 1, q)) { primary(q, b1o, b1d); b1q = q; n_buf = 2; }
@@ -410,8 +410,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RT_SMA
                 const SmallShade sh = lds_shade[h.leaf];
                 const uint32_t mtype = sh.meta & 0xff;
                 const f3 p = ro + rd * h.t;
-                const f3 gv = f3mk(sh.g[0], sh.g[1], sh.g[2]);
-                const f3 n_out = (sh.meta & RTC_SF_SPHERE) ? (p - gv) * sh.g[3] : gv;
+                // outward normal: the record holds (n, 0) for a rect and (-c / r, 1 / r) for a sphere (rtc_api.cpp upload_scene), so that
+                // n_out = p * g3 + g is the rect's n or the sphere's (p - c) / r without a branch or a select
+                const f3 n_out = f3mk(__builtin_fmaf(p.x, sh.g[3], sh.g[0]), __builtin_fmaf(p.y, sh.g[3], sh.g[1]), __builtin_fmaf(p.z, sh.g[3], sh.g[2]));
                 bool front = dot(rd, n_out) < 0.0f;                        // hit_record_set_facenormal, hittable.c:13-16
                 const f3 n = front ? n_out : -n_out;
                 if (sh.meta & RTC_SF_FORCED_FRONT) front = true;            // translate/rotate re-face an already faced normal (F11)
@@ -465,9 +466,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RT_SMA
             ++depth;
             if (done || depth >= P.max_depth) {
                 alive = false;
-                const bool finite = (fabsf(L.x) < 3.0e38f) && (fabsf(L.y) < 3.0e38f) && (fabsf(L.z) < 3.0e38f);
+                // finite and not all zero in two compares: |x| + |y| + |z| is NaN or inf when a component is, 0 when all are
                 // (most paths of a scene with a black background end with nothing to add: no LDS traffic for those)
-                if (finite && (L.x != 0.0f || L.y != 0.0f || L.z != 0.0f)) { atomicAdd(&tile_sum[cur_pix], L.x); atomicAdd(&tile_sum[64 + cur_pix], L.y); atomicAdd(&tile_sum[128 + cur_pix], L.z); }
+                const float mag = fabsf(L.x) + fabsf(L.y) + fabsf(L.z);
+                if ((mag > 0.0f) & (mag < 3.0e38f)) { atomicAdd(&tile_sum[cur_pix], L.x); atomicAdd(&tile_sum[64 + cur_pix], L.y); atomicAdd(&tile_sum[128 + cur_pix], L.z); }
             }
         }
     }

@@ -322,7 +322,13 @@ static rtc_scene *upload_scene(rtc_scene *s, const char *who) {
         int counts[6];
         const std::vector<SmallRec> prog = build_small_program(fs, counts);
         e = s->small_prog.upload(prog.data(), prog.size() * sizeof(SmallRec));
-        if (e == hipSuccess) e = s->small_shade.upload(fs.small_shade.data(), fs.small_shade.size() * sizeof(SmallShade));
+        // the kernel's copy of the shading records: g = (n, 0) for a rect, (-c / r, 1 / r) for a sphere -- n_out = p * g3 + g (kernels_small.hip)
+        std::vector<SmallShade> shade = fs.small_shade;
+        for (SmallShade &sh : shade) {
+            if (sh.meta & RTC_SF_SPHERE) for (int k = 0; k < 3; k++) sh.g[k] = -sh.g[k] * sh.g[3];
+            else sh.g[3] = 0.0f;
+        }
+        if (e == hipSuccess) e = s->small_shade.upload(shade.data(), shade.size() * sizeof(SmallShade));
         SmallScene &m = s->small;
         m.prog = (const SmallRec *)s->small_prog.p; m.shade = (const SmallShade *)s->small_shade.p;
         m.n_box = counts[0]; m.n_xbox = counts[1]; m.n_xy = counts[2]; m.n_xz = counts[3]; m.n_yz = counts[4]; m.n_sphere = counts[5]; m.n_recs = (int)prog.size();

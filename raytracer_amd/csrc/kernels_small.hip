@@ -35,6 +35,11 @@ namespace {
 
 struct SmallHit { float t; int leaf; };
 
+// (t, leaf) <- (nt, nleaf) where `take`.  (hipcc emits the pair as two v_cndmask_b32_e32 ..., vcc in a row, which a micro-benchmark shows
+// stalling a lone wave for ~40 cycles; issuing the second one in VOP3 form with the mask in an SGPR pair -- inline assembly -- made the
+// kernel 2 % SLOWER: with 7 waves resident the bubble is hidden and the extra scalar instruction is not.)
+RT_DEV void take_hit(bool take, float nt, int nleaf, SmallHit &h) { h.t = take ? nt : h.t; h.leaf = take ? nleaf : h.leaf; }
+
 typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
 RT_DEV float recf(const u32x16 &R, int k) { return __uint_as_float(R[k]); }
 RT_DEV f3 rcp3(f3 d) { return f3mk(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z)); }
@@ -57,8 +62,7 @@ RT_DEV void small_rect(float k, float ca, float cb, float ha, float hb, int id, 
     const float ea = fabsf(__builtin_fmaf(da, t, oa) - ca) - ha, eb = fabsf(__builtin_fmaf(db, t, ob) - cb) - hb;
     const float outside = fmaxf(ea, eb);
     const float viol = fmaxf(outside, fmaxf(tmin - t, t - h.t));
-    const bool hit = (viol <= 0.0f) & (id != src);
-    h.t = hit ? t : h.t; h.leaf = hit ? id : h.leaf;
+    take_hit((viol <= 0.0f) & (id != src), t, id, h);
     if (PDF && light) pdf += ((outside <= 0.0f) & (t >= 0.0001f)) ? (t * t) * (fabsf(in) * inv_area) : 0.0f;
 }
 // the two rects of a pair record; the caller has split the ray by the run's axis
@@ -98,7 +102,7 @@ RT_DEV void small_box(const u32x16 &R, f3 o, f3 inv, float tmin, int src, SmallH
     const float t = enter ? t_in : t_out;
     const uint32_t id = enter ? id_in : id_out;
     const bool hit = (t_in <= t_out) & (t >= tmin) & (t <= h.t) & (id != 0xffu) & (id != (uint32_t)src);
-    h.t = hit ? t : h.t; h.leaf = hit ? (int)id : h.leaf;
+    take_hit(hit, t, (int)id, h);
 }
 // world space, closest-approach form (rt_core.hpp sphere_t<float>); |dw| = 1 (every ray of this kernel): the quadratic's a is 1.
 // `src` = leaf the ray starts on: a sphere left behind has the roots {0, 2 tc} (rt_core.hpp sphere_leave_t).
@@ -116,8 +120,7 @@ RT_DEV void small_sphere(const u32x16 &R, f3 ow, f3 dw, float tmin, int src, Sma
     const float t0 = from ? 2.0f * tc : tc - sq, t1 = tc + sq;
     const bool ok0 = (t0 >= tmin) & (t0 <= h.t), ok1 = (t1 >= tmin) & (t1 <= h.t) & !from;
     const float t = ok0 ? t0 : t1;
-    const bool hit = (from | (q >= 0.0f)) & (ok0 | ok1);
-    h.t = hit ? t : h.t; h.leaf = hit ? id : h.leaf;
+    take_hit((from | (q >= 0.0f)) & (ok0 | ok1), t, id, h);
     if (PDF && (head & (1u << 16))) {                            // wave-uniform: this sphere is a light-list entry (hittable.c:760-768)
         const float need = 0.001f - tc;                          // the far root tc + sqrt(q) decides alone: small_light_pdf_one
         const bool seen = !(q < 0.0f) & (!(need > 0.0f) | !(q < need * need));
@@ -340,7 +343,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RT_SMA
     auto primary = [&](int q, f3 &o, f3 &d) {                             // main.c:150-152 + camera.c:46-53
         int pix; uint32_t smp; locate(q, pix, smp);
         const int px = tx0 + (pix & 7), py = ty0 + (pix >> 3);
-        const Rng4 c = rng_block((uint32_t)(py * P.width + px), smp, RT_TAG_CAMERA, P.seed_lo, P.seed_hi);
+const Rng4 c = rng_block((uint32_t)(py * P.width + px), smp, RT_TAG_CAMERA, P.seed_lo, P.seed_hi);
         const SmallArgs &t = small_args_again(q_next);                            // the camera's constants: read here, not held across the loop
         f3 dir;
         if (LENS) {
@@ -401,11 +404,14 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RT_SMA
             }
         }
         if (alive) {
-            bool done;
+            // `done` is an integer in a VGPR on purpose: a bool that is set in divergent arms lives in an SGPR mask, and every assignment to
+            // it costs three scalar instructions to merge -- scalar instructions take issue slots like vector ones.  The
+            // material arms are separate ifs (they exclude each other by construction), not an else-if chain: no else-mask bookkeeping.
+            int done = 0;
             f3 L = f3mk(0, 0, 0);   // a path collects radiance once, where it ends (emitter or background): nothing to carry between bounces
             if (h.leaf < 0) {
                 L = T * (INTEGRATOR == 2 ? sky_color(rd) : bg);
-                done = true;
+                done = 1;
             } else {
                 const SmallShade sh = lds_shade[h.leaf];
                 const uint32_t mtype = sh.meta & 0xff;
@@ -419,21 +425,22 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RT_SMA
                 if (sh.meta & RTC_SF_FLIP) front = !front;                  // flip_face_hit, hittable.c:587-591
                 const f3 col = f3mk(sh.rgb[0], sh.rgb[1], sh.rgb[2]);
                 Rng4 xi = rng_block(pixel, s_cur, (uint32_t)depth, P.seed_lo, P.seed_hi);
-                done = false;
                 f3 nd = rd;
                 if (mtype == RTC_MAT_LIGHT) {                               // material.c:229-235 (03: front face only, F15); no scatter
                     if (INTEGRATOR == 1 || (INTEGRATOR == 0 && front)) L = T * col;
-                    done = true;
-                } else if (mtype == RTC_MAT_METAL) {                        // material.c:130-138 / 02 material.c:132-141
+                    done = 1;
+                }
+                if (mtype == RTC_MAT_METAL) {                               // material.c:130-138 / 02 material.c:132-141
                     nd = reflect(rd, n);                                     // |rd| = 1
                     if (ss.any_fuzz) nd = normalize(nd + uniform_ball(xi.x, xi.y, xi.z) * sh.param);
-                    if (INTEGRATOR != 0 && !(dot(nd, n) > 0.0f)) done = true;
+                    if (INTEGRATOR != 0 && !(dot(nd, n) > 0.0f)) done = 1;
                     T = T * col;
-                } else if (mtype == RTC_MAT_DIELECTRIC) {                   // material.c:144-162
+                }
+                if (mtype == RTC_MAT_DIELECTRIC)                            // material.c:144-162
                     nd = small_dielectric_dir(sh.param, sh.pad[0], sh.pad[1], rd, n, front, xi.x);
-                } else if (mtype == RTC_MAT_ISOTROPIC) {
-                    done = true;                                            // only reachable through a medium; none in a small scene
-                } else if (INTEGRATOR != 0) {                               // 02 material.c:120-128: normal + random unit vector
+                if (mtype == RTC_MAT_ISOTROPIC) done = 1;                   // only reachable through a medium; none in a small scene
+                if (mtype == RTC_MAT_LAMBERTIAN) {
+                if (INTEGRATOR != 0) {                                      // 02 material.c:120-128: normal + random unit vector
                     nd = n + uniform_sphere(xi.x, xi.y);
                     if (fabsf(nd.x) < 1e-8f && fabsf(nd.y) < 1e-8f && fabsf(nd.z) < 1e-8f) nd = n;
                     nd = normalize(nd);
@@ -451,20 +458,21 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RT_SMA
                     nd = nd * __builtin_amdgcn_rsqf(len2(nd));              // unit from here on: the pdfs and the next bounce's tests drop |v|
                     const float pdf_cos = lambert_pdf(n, nd);                         // pdf.c:100-103 == material.c:205-208
                     if (fused) {                                            // the light-list pdf of nd arrives with the next intersection
-                        if (!(pdf_cos > 0.0f)) done = true;
+                        if (!(pdf_cos > 0.0f)) done = 1;
                         else { T = T * col; pend = pdf_cos; }
                     } else {
                     const float pdf_light = sc.n_lights > 0 ? small_light_pdf_sum(sc, p, nd) : 0.0f;   // x 1 / n_lights below
                     const float pdf_val = P.light_weight_each * pdf_light + P.cosine_weight * pdf_cos;  // pdf.c:119-121
                     // scattering pdf 0: the reference recurses and multiplies by 0; pdf_val 0: 0/0 (scrubbed) -- nothing more arrives
-                    if (!(pdf_cos > 0.0f) || !(pdf_val > 0.0f)) done = true;
+                    if (!(pdf_cos > 0.0f) || !(pdf_val > 0.0f)) done = 1;
                     else T = T * (col * (pdf_cos * __builtin_amdgcn_rcpf(pdf_val)));
                     }
+                }
                 }
                 ro = p; rd = nd; src = h.leaf;
             }
             ++depth;
-            if (done || depth >= P.max_depth) {
+            if ((done != 0) | (depth >= P.max_depth)) {
                 alive = false;
                 // finite and not all zero in two compares: |x| + |y| + |z| is NaN or inf when a component is, 0 when all are
                 // (most paths of a scene with a black background end with nothing to add: no LDS traffic for those)

@@ -103,6 +103,11 @@ constexpr int ITERS = 16384;
 #define T_M10(D, A, B) M_MUL(D, A) "s_mov_b32 s22, s23\n"
 #define T_M11(D, A, B) M_MAX(D, A) "s_mov_b32 s22, s23\n s_mov_b32 s24, s23\n"
 #define T_M12(D, A, B) M_MUL(D, A) "s_mov_b32 s22, s23\n s_mov_b32 s24, s23\n"
+#define T_M13(D, A, B) M_MUL(D, A) M_MUL(D, B) M_MUL(D, A) M_MUL(D, B) M_MUL(D, A) M_MUL(D, B) M_MUL(D, A) "v_rcp_f32 v" #D ", v" #D "\n"
+#define T_M14(D, A, B) "v_rcp_f32 v20, v" #A "\n" M_MUL(D, A) M_MUL(D, B) M_MUL(D, A)
+#define T_M15(D, A, B) "v_rcp_f32 v20, v" #A "\n" M_MAX(D, A) M_MUL(D, B) M_MAX(D, A)
+#define T_M16(D, A, B) "v_rcp_f32 v20, v" #A "\n v_rcp_f32 v21, v" #B "\n" M_MUL(D, A) M_MUL(D, B) M_MUL(D, A) M_MUL(D, B) M_MUL(D, A) M_MUL(D, B)
+#define T_M17(D, A, B) "v_sqrt_f32 v20, v" #A "\n" M_MUL(D, A) M_MUL(D, B) M_MUL(D, A) M_MUL(D, B) M_MUL(D, A) M_MUL(D, B) M_MUL(D, A)
 #define CASE_M(N, T) if (OP == N) { asm volatile(REP8(GROUP(T)) :: "s"(seed) : ACC8, "vcc", "scc", "s22", "s23", "s24"); }
 #define CASE_V(N, T) if (OP == N) { asm volatile(REP8(GROUP(T)) ::: ACC8, "vcc"); }
 #define CASE_S(N, T) if (OP == N) { asm volatile(REP8(GROUP(T)) :: "s"(seed) : ACC8, "vcc"); }
@@ -166,6 +171,11 @@ template <int OP> __global__ void __launch_bounds__(256) k(unsigned long long *c
         if (OP == 96) { asm volatile(REP8(GROUP(T_MUL4_SALU)) ::: ACC8, "s22", "scc"); }
         CASE_M(100, T_M1) CASE_M(101, T_M2) CASE_M(102, T_M3) CASE_M(103, T_M4) CASE_M(104, T_M5) CASE_M(105, T_M6) CASE_M(106, T_M7) CASE_M(107, T_M8)
         CASE_M(108, T_M9) CASE_M(109, T_M10) CASE_M(110, T_M11) CASE_M(111, T_M12)
+        if (OP == 112) { asm volatile(REP8(GROUP(T_M13)) ::: ACC8); }
+        if (OP == 113) { asm volatile(REP8(GROUP(T_M14)) ::: ACC8, "v20"); }
+        if (OP == 114) { asm volatile(REP8(GROUP(T_M15)) ::: ACC8, "v20"); }
+        if (OP == 115) { asm volatile(REP8(GROUP(T_M16)) ::: ACC8, "v20", "v21"); }
+        if (OP == 116) { asm volatile(REP8(GROUP(T_M17)) ::: ACC8, "v20"); }
         CASE_V(73, T_LDEXP) CASE_V(74, T_FRACT) CASE_V(75, T_FLOOR)
     }
     const unsigned long long t1 = __builtin_readcyclecounter();
@@ -245,6 +255,8 @@ int main() {
     run<100>("mix: v_mul + v_max", 64); run<101>("mix: 2 v_mul + v_max", 64); run<102>("mix: v_mul + 2 v_max", 64); run<103>("mix: v_mul + v_mul(SGPR)", 64);
     run<104>("mix: v_mul + v_cmp", 64); run<105>("mix: 3 v_mul + v_rcp", 64); run<106>("mix: 2 v_mul + s_add", 64); run<107>("mix: 4 v_mul + s_add", 64);
     run<108>("mix: v_max + s_add", 64); run<109>("mix: v_mul + s_mov", 64); run<110>("mix: v_max + 2 s_mov", 64); run<111>("mix: v_mul + 2 s_mov", 64);
+    run<112>("mix: 7 v_mul + dependent v_rcp", 64); run<113>("mix: independent v_rcp + 3 v_mul", 64); run<114>("mix: independent v_rcp + max, mul, max", 64);
+    run<115>("mix: 2 independent v_rcp + 6 v_mul", 64); run<116>("mix: independent v_sqrt + 7 v_mul", 64);
     run<30>("v_add_u32", 64); run<31>("v_lshlrev_b32", 64); run<32>("v_lshrrev_b32", 64); run<33>("v_and_b32", 64); run<43>("v_bfe_u32", 64); run<68>("v_bfi_b32", 64); run<44>("v_perm_b32", 64);
     run<45>("v_and_or_b32", 64); run<46>("v_lshl_add_u32", 64); run<47>("v_add3_u32", 64);
     run<34>("v_mul_lo_u32", 64); run<35>("v_mul_hi_u32", 64); run<65>("v_mul_u32_u24", 64); run<66>("v_mad_u32_u24", 64); run<36>("v_mad_u64_u32 (32 per iteration)", 32);

@@ -221,12 +221,18 @@ RT_DEV float small_light_pdf_sum(const SceneT<float> &sc, f3 o, f3 v) {
 // material.c:144-157 for a unit incoming direction (rt_shade.hpp dielectric_dir without its normalisation); the result is a unit vector
 // (1 / ir and Schlick's r0 come from the shading record: both are constants of the material)
 RT_DEV f3 small_dielectric_dir(float ir, float inv_ir, float r0, f3 ud, f3 n, bool front, float xi) {
+    // Both outcomes are a ud + b n -- reflect (vec3.c:26): (1, 2 c), c = -ud.n; refract (vec3.c:44-50): (eta, eta cos + k), k = -sqrt|1 - |perp|^2|,
+    // |perp|^2 = eta^2 |ud + n cos|^2 = eta^2 (1 - 2 cos c + cos^2) for unit ud, n -- so the choice is two selects, not a divergent branch
+    // around two vector expressions (the branch cost twenty scalar instructions; both sides ran for a mixed wave anyway).
     const float ratio = front ? inv_ir : ir;
-    const float cos_theta = fminf(dot(-ud, n), 1.0f);
+    const float c = -dot(ud, n), cos_theta = fminf(c, 1.0f);
     const float sin_theta = __builtin_amdgcn_sqrtf(fmaxf(0.0f, 1.0f - cos_theta * cos_theta));
     const float m = 1.0f - cos_theta, m2 = m * m;
-    if (ratio * sin_theta > 1.0f || r0 + (1.0f - r0) * (m2 * m2 * m) > xi) return reflect(ud, n);   // material.c:142,152
-    return refract(ud, n, ratio);
+    const bool refl = (ratio * sin_theta > 1.0f) | (r0 + (1.0f - r0) * (m2 * m2 * m) > xi);   // material.c:142,152
+    const float perp2 = (ratio * ratio) * (1.0f - 2.0f * cos_theta * c + cos_theta * cos_theta);
+    const float k = -__builtin_amdgcn_sqrtf(fabsf(1.0f - perp2));
+    const float a = refl ? 1.0f : ratio, b = refl ? 2.0f * c : ratio * cos_theta + k;
+    return ud * a + n * b;
 }
 // Duff et al. 2017 branch-free orthonormal basis (any basis around w gives the same uniform azimuth as onb.c:7-12)
 RT_DEV void basis_around(f3 w, f3 &u, f3 &v) {
@@ -331,19 +337,20 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RT_SMA
     // throughput is completed there -- before anything reads it.  pend = 0: nothing pending.
     constexpr bool fused = FUSED && INTEGRATOR == 0;
     float pend = 0.0f;
-    auto locate = [&](int q, int &pix, uint32_t &smp) { pix = q & 63; smp = (uint32_t)(s_lo + (q >> 6)); };   // path number q = sample * 64 + pixel
+    constexpr int kVoid = 1 << 30;   // flag on a buffered path number: its pixel is outside the image (ragged right / top edge), nothing to trace
+    auto locate = [&](int q, int &pix, uint32_t &smp) { pix = q & 63; smp = (uint32_t)(s_lo + ((q & (kVoid - 1)) >> 6)); };   // path number q = sample * 64 + pixel
     // Primary rays are generated ahead, two per lane (b0 is used first): a third of the lanes ends a path in every
     // iteration, so generating on demand runs the camera code (a Philox block and the ray set-up) in EVERY iteration
     // for a third of the wave; filled only when some lane has run dry, it runs every few iterations for most of it
     // (a third buffered ray changes nothing; a wave-wide batch of 64 rays through an LDS ring ran the camera code at full
     // width but made every path start wait for an LDS read: 5.6 % slower).  A pixel outside the image (ragged right / top
-    // edge) buffers a zero direction.
+    // edge) is buffered with the kVoid flag on its path number.
     f3 b0d = rd, b1d = rd, b0o = ro, b1o = ro;
     int b0q = 0, b1q = 0, n_buf = 0;                                      // buffered paths and their numbers
-    auto primary = [&](int q, f3 &o, f3 &d) {                             // main.c:150-152 + camera.c:46-53
+    auto primary = [&](int &q, f3 &o, f3 &d) {                            // main.c:150-152 + camera.c:46-53
         int pix; uint32_t smp; locate(q, pix, smp);
         const int px = tx0 + (pix & 7), py = ty0 + (pix >> 3);
-const Rng4 c = rng_block((uint32_t)(py * P.width + px), smp, RT_TAG_CAMERA, P.seed_lo, P.seed_hi);
+        const Rng4 c = rng_block((uint32_t)(py * P.width + px), smp, RT_TAG_CAMERA, P.seed_lo, P.seed_hi);
         const SmallArgs &t = small_args_again(q_next);                            // the camera's constants: read here, not held across the loop
         f3 dir;
         if (LENS) {
@@ -357,7 +364,8 @@ const Rng4 c = rng_block((uint32_t)(py * P.width + px), smp, RT_TAG_CAMERA, P.se
                        __builtin_fmaf(t.P.cam_vs[2], fy, __builtin_fmaf(t.P.cam_hs[2], fx, t.P.cam_base[2])));
             o = f3mk(0, 0, 0);                                              // (not buffered: the bounce loop takes the camera's origin)
         }
-        d = (px < t.P.width && py < t.P.height) ? normalize(dir) : f3mk(0, 0, 0);   // unit directions throughout the bounce loop
+        d = normalize(dir);                                                 // unit directions throughout the bounce loop
+        q |= ((px < t.P.width) & (py < t.P.height)) ? 0 : kVoid;            // (no branch around the camera code: such pixels are rare)
     };
     // the next paths go to the lanes of `want`, in lane order
     auto hand_out = [&](bool want, int &q) -> bool {
@@ -376,13 +384,14 @@ const Rng4 c = rng_block((uint32_t)(py * P.width + px), smp, RT_TAG_CAMERA, P.se
             if (hand_out(n_buf == 1, q)) { primary(q, b1o, b1d); b1q = q; n_buf = 2; }
         }
         if (!alive && n_buf > 0) {
-            locate(b0q, cur_pix, s_cur); --n_buf;
+            const int path_q = b0q;
+            locate(path_q, cur_pix, s_cur); --n_buf;
             pixel = (uint32_t)((ty0 + (cur_pix >> 3)) * P.width + tx0 + (cur_pix & 7));
             rd = b0d; b0d = b1d; b0q = b1q;
             if (LENS) { ro = b0o; b0o = b1o; } else ro = f3mk(a.cam.origin[0], a.cam.origin[1], a.cam.origin[2]);
             T = f3mk(1, 1, 1);
             depth = 0; src = -1; pend = 0.0f;
-            alive = rd.x != 0.0f || rd.y != 0.0f || rd.z != 0.0f;          // a pixel outside the image: nothing to trace
+            alive = path_q < kVoid;                                         // a pixel outside the image: nothing to trace
         }
         // (a buffered ray may be void -- a pixel outside the image: a wave whose lanes all drew one goes on while rays are buffered)
         if (__builtin_amdgcn_ballot_w64(alive || n_buf > 0) == 0) break;
@@ -391,17 +400,19 @@ const Rng4 c = rng_block((uint32_t)(py * P.width + px), smp, RT_TAG_CAMERA, P.se
         if (alive) {
             float pdf_ray;
             h = small_closest_hit<fused>(ss, ro, rd, 0.001f, src, pdf_ray);  // ray.c:56
-            ++nrays;
-            if (fused && pend > 0.0f) {                               // complete the previous bounce: T *= pdf_cos / pdf_val (ray.c:80-83)
+            if (fused) {                                              // complete the previous bounce: T *= pdf_cos / pdf_val (ray.c:80-83)
                 // (pend > 0 and a cosine weight > 0 make pdf_val > 0.  A pdf_val of 0 or NaN -- an underflowed mixture, a ray from inside a
                 // light sphere -- is the reference's 0/0: nothing more arrives from this path.  The stand-alone light loop ends such a path at
                 // the bounce that made the direction; here the direction's ray has just been traced to learn its pdf, so the path ends now,
-                // carrying nothing, and that one ray is not counted: both forms report the same paths and the same rays.)
+                // carrying nothing, and that one ray is not counted: both forms report the same paths and the same rays.  No branch: selects.)
                 const float pdf_val = P.light_weight_each * pdf_ray + P.cosine_weight * pend;
-                if (!(pdf_val > 0.0f)) { alive = false; --nrays; }
-                T = T * (pend * __builtin_amdgcn_rcpf(pdf_val));
+                const bool pending = pend > 0.0f, dead = pending & !(pdf_val > 0.0f);
+                const float f = pending ? pend * __builtin_amdgcn_rcpf(pdf_val) : 1.0f;
+                T = T * f;
                 pend = 0.0f;
-            }
+                nrays += dead ? 0u : 1u;
+                alive = !dead;
+            } else ++nrays;
         }
         if (alive) {
             // `done` is an integer in a VGPR on purpose: a bool that is set in divergent arms lives in an SGPR mask, and every assignment to

@@ -277,80 +277,91 @@ RT_DEV float schlick(float cosine, float ref_idx) {                             
     return r0 + (1.0f - r0) * (m2 * m2 * m);
 }
 RT_DEV f3 dielectric_dir(float ir, f3 dir, const RecT<float> &rec, float xi) {          // material.c:144-157
+    // Both outcomes are a ud + b n -- reflect (vec3.c:26): (1, 2 c) with c = -ud.n; refract (vec3.c:44-50): (eta, eta cos + k),
+    // k = -sqrt|1 - |perp|^2|, |perp|^2 = eta^2 |ud + n cos|^2 = eta^2 (1 - 2 cos c + cos^2) for unit ud and n -- so the choice is two
+    // selects instead of a divergent branch around two vector expressions (both sides ran for a mixed wave anyway, and the branch's
+    // mask bookkeeping is scalar instructions that take issue slots like vector ones).
     const float ratio = rec.front ? __builtin_amdgcn_rcpf(ir) : ir;
     const f3 ud = normalize(dir);
-    const float cos_theta = fminf(dot(-ud, rec.n), 1.0f);
+    const float c = -dot(ud, rec.n), cos_theta = fminf(c, 1.0f);
     const float sin_theta = __builtin_amdgcn_sqrtf(fmaxf(0.0f, 1.0f - cos_theta * cos_theta));
-    if (ratio * sin_theta > 1.0f || schlick(cos_theta, ratio) > xi) return reflect(ud, rec.n);
-    return refract(ud, rec.n, ratio);
+    const bool refl = (ratio * sin_theta > 1.0f) | (schlick(cos_theta, ratio) > xi);
+    const float perp2 = (ratio * ratio) * (1.0f - 2.0f * cos_theta * c + cos_theta * cos_theta);
+    const float k = -__builtin_amdgcn_sqrtf(fabsf(1.0f - perp2));
+    const float a = refl ? 1.0f : ratio, b = refl ? 2.0f * c : ratio * cos_theta + k;
+    return ud * a + rec.n * b;
 }
 
 // Shade one hit.  integrator 0: ray.c:58-83 in loop form (L += T*emitted; T *= att*scattering_pdf/pdf_val).
 // integrator 1/2: 02 main.c:54-62 / 01 main.c:45-56 (T *= attenuation).  xi = this bounce's Philox block.
 // `m` = the material record; resolved = its texture is the constant m.albedo (a leaf_shade record, rtc_tables.h): no table is
 // read at all then.
+// One exit: the material arms are separate ifs (they exclude each other) that leave the next direction, the throughput factor and an
+// integer status in registers -- with early returns out of an else-if chain the compiler keeps "which lanes have returned" in scalar
+// masks and spends three scalar instructions on every merge (the small-scene kernel lost 5 % of its time to that).
+// After RT_TERMINATE the callers read ps.L only.
 template <bool NOISE = true>
 RT_DEV int shade_hit_mat(const SceneT<float> &sc, PathState &ps, const RecT<float> &rec, const MaterialT<float> &m, bool resolved, int integrator,
                          float light_weight, const Rng4 &xi) {
     auto tex = [&]() { return resolved ? f3mk(m.albedo[0], m.albedo[1], m.albedo[2]) : texture_value<NOISE>(sc, m.tex, rec.u, rec.v, rec.p); };
     const f3 d = ps.ray.d;
-    RayT<float> next; next.o = rec.p; next.time = ps.ray.time;
+    int status = RT_CONTINUE;
+    f3 nd = d, tm = f3mk(1, 1, 1);                                                      // next direction, throughput factor
     // lambertian (02 / 01), fuzzy metal and the isotropic phase function all start from ONE uniform point on the unit sphere: drawn
-    // here, ahead of the switch, so that a wave whose lanes stand on different materials runs the sqrt / sin / cos sequence once
+    // here, ahead of the arms, so that a wave whose lanes stand on different materials runs the sqrt / sin / cos sequence once
     const bool ball = (m.type == RTC_MAT_METAL && m.param > 0.0f) || m.type == RTC_MAT_ISOTROPIC;
     f3 us = f3mk(0, 0, 0);
     if (ball || (m.type == RTC_MAT_LAMBERTIAN && integrator != 0)) us = uniform_sphere(xi.x, xi.y);
     if (ball) us = us * ball_radius(xi.z);
     if (m.type == RTC_MAT_LIGHT) {                                                     // material.c:229-235 (03: front face only, F15)
         if (integrator != 2 && (integrator == 1 || rec.front)) ps.L = ps.L + ps.T * tex();
-        return RT_TERMINATE;                                                           // material_light_scatter returns 0
+        status = RT_TERMINATE;                                                         // material_light_scatter returns 0
     }
     if (m.type == RTC_MAT_METAL) {                                                     // material.c:130-138 / 02 :132-141
         const f3 reflected = reflect(normalize(d), rec.n);
-        next.d = m.param > 0.0f ? reflected + us * m.param : reflected;
-        if (integrator != 0 && !(dot(next.d, rec.n) > 0.0f)) return RT_TERMINATE;      // 02/01: absorbed
-        ps.T = ps.T * f3mk(m.albedo[0], m.albedo[1], m.albedo[2]);
-        ps.ray = next; return RT_CONTINUE;
+        nd = m.param > 0.0f ? reflected + us * m.param : reflected;
+        if (integrator != 0 && !(dot(nd, rec.n) > 0.0f)) status = RT_TERMINATE;        // 02/01: absorbed
+        tm = f3mk(m.albedo[0], m.albedo[1], m.albedo[2]);
     }
-    if (m.type == RTC_MAT_DIELECTRIC) {
-        next.d = dielectric_dir(m.param, d, rec, xi.x);
-        ps.ray = next; return RT_CONTINUE;                                             // attenuation (1,1,1)
-    }
+    if (m.type == RTC_MAT_DIELECTRIC) nd = dielectric_dir(m.param, d, rec, xi.x);      // attenuation (1,1,1)
     if (m.type == RTC_MAT_ISOTROPIC) {                                                 // 02 material.c:173-177; 03's is UB (F14) -> absorb
-        if (integrator == 0) return RT_TERMINATE;
-        next.d = us;
-        ps.T = ps.T * tex();
-        ps.ray = next; return RT_CONTINUE;
+        if (integrator == 0) status = RT_TERMINATE;
+        nd = us;
+        tm = tex();
     }
-    // lambertian
-    const f3 att = tex();
-    if (integrator != 0) {                                                             // 02 material.c:120-128
-        f3 dir = rec.n + us;
-        if (fabsf(dir.x) < 1e-8f && fabsf(dir.y) < 1e-8f && fabsf(dir.z) < 1e-8f) dir = rec.n;
-        next.d = dir; ps.T = ps.T * att; ps.ray = next; return RT_CONTINUE;
+    if (m.type == RTC_MAT_LAMBERTIAN) {
+        const f3 att = tex();
+        if (integrator != 0) {                                                         // 02 material.c:120-128
+            f3 dir = rec.n + us;
+            if (fabsf(dir.x) < 1e-8f && fabsf(dir.y) < 1e-8f && fabsf(dir.z) < 1e-8f) dir = rec.n;
+            nd = dir; tm = att;
+        } else {
+            // 03: mixture of the light-list pdf and the cosine pdf (ray.c:66-83, pdf.c:119-121,175-181)
+            const Onb uvw = onb_from_w(rec.n);
+            f3 dir;
+            if (sc.n_lights > 0 && xi.x < light_weight) {
+                int pick = (int)((float)sc.n_lights * xi.y);                           // random_int(0,n-1), utils.h:26
+                pick = pick < sc.n_lights ? pick : sc.n_lights - 1;
+                dir = light_random_one(sc.lights[pick], rec.p, xi.z, xi.w);
+            } else {                                                                   // random_cosine_direction, vec3.c:97-107
+                const float r2 = xi.w, sr = __builtin_amdgcn_sqrtf(r2);
+                dir = onb_local(uvw, f3mk(cos2pi(xi.z) * sr, sin2pi(xi.z) * sr, __builtin_amdgcn_sqrtf(1.0f - r2)));
+            }
+            const f3 udir = normalize(dir);
+            const float pdf_cos = lambert_pdf(uvw.w, udir);                             // pdf.c:100-103
+            const float pdf_light = sc.n_lights > 0 ? light_list_pdf(sc, rec.p, dir) : 0.0f;
+            const float pdf_val = light_weight * pdf_light + (1.0f - light_weight) * pdf_cos;   // pdf.c:119-121
+            const float spdf = lambert_pdf(rec.n, udir);                                // material.c:205-208
+            // spdf == 0: the reference keeps recursing but multiplies the child by 0; pdf_val == 0: 0/0 = NaN in the
+            // reference (scrubbed to a black sample).  Either way nothing more can reach the pixel.
+            if (!(spdf > 0.0f) | !(pdf_val > 0.0f)) status = RT_TERMINATE;
+            tm = att * (spdf * __builtin_amdgcn_rcpf(pdf_val));
+            nd = dir;
+        }
     }
-    // 03: mixture of the light-list pdf and the cosine pdf (ray.c:66-83, pdf.c:119-121,175-181)
-    const Onb uvw = onb_from_w(rec.n);
-    f3 dir;
-    if (sc.n_lights > 0 && xi.x < light_weight) {
-        int pick = (int)((float)sc.n_lights * xi.y);                                   // random_int(0,n-1), utils.h:26
-        pick = pick < sc.n_lights ? pick : sc.n_lights - 1;
-        dir = light_random_one(sc.lights[pick], rec.p, xi.z, xi.w);
-    } else {                                                                           // random_cosine_direction, vec3.c:97-107
-        const float r2 = xi.w, sr = __builtin_amdgcn_sqrtf(r2);
-        dir = onb_local(uvw, f3mk(cos2pi(xi.z) * sr, sin2pi(xi.z) * sr, __builtin_amdgcn_sqrtf(1.0f - r2)));
-    }
-    const f3 udir = normalize(dir);
-    const float pdf_cos = lambert_pdf(uvw.w, udir);                                     // pdf.c:100-103
-    const float pdf_light = sc.n_lights > 0 ? light_list_pdf(sc, rec.p, dir) : 0.0f;
-    const float pdf_val = light_weight * pdf_light + (1.0f - light_weight) * pdf_cos;   // pdf.c:119-121
-    const float spdf = lambert_pdf(rec.n, udir);                                        // material.c:205-208
-    // spdf == 0: the reference keeps recursing but multiplies the child by 0; pdf_val == 0: 0/0 = NaN in the
-    // reference (scrubbed to a black sample).  Either way nothing more can reach the pixel.
-    if (!(spdf > 0.0f) || !(pdf_val > 0.0f)) return RT_TERMINATE;
-    ps.T = ps.T * (att * (spdf * __builtin_amdgcn_rcpf(pdf_val)));
-    next.d = dir; ps.ray = next;
-    return RT_CONTINUE;
+    ps.T = ps.T * tm;
+    ps.ray.o = rec.p; ps.ray.d = nd;
+    return status;
 }
 
 template <bool NOISE = true>

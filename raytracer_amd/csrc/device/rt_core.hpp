@@ -233,8 +233,8 @@ RT_DEV bool sphere_roots_f32(V3<float> c, float rad, const RayT<float> &r, float
     const V3<float> oc = r.o - c;
     const float inv_a = __builtin_amdgcn_rcpf(len2(r.d));
     const float tc = -dot(oc, r.d) * inv_a;
-    const V3<float> l = oc + r.d * tc;
-    const float q = (rad * rad - len2(l)) * inv_a;
+    const V3<float> l = mk3<float>(__builtin_fmaf(r.d.x, tc, oc.x), __builtin_fmaf(r.d.y, tc, oc.y), __builtin_fmaf(r.d.z, tc, oc.z));
+    const float q = __builtin_fmaf(rad, rad, -len2(l)) * inv_a;
     const float sq = __builtin_amdgcn_sqrtf(fmaxf(q, 0.0f));
     const float t0 = from_here ? 2.0f * tc : tc - sq, t1 = tc + sq;
     const bool ok0 = (t0 >= tmin) & (t0 <= tmax), ok1 = (t1 >= tmin) & (t1 <= tmax) & !from_here;
@@ -357,15 +357,15 @@ RT_DEV void bvh_trip_tab(const SceneT<float> &sc, const float4 *node_tab, const 
 }
 template <int KINDS = RTC_KIND_ALL, typename Stack, typename MediumFn>
 RT_DEV HitS bvh_closest_hit_tab(const SceneT<float> &sc, const float4 *node_tab, const float4 *leaf_tab, const RayT<float> &r, float tmin, float tmax,
-                                Stack &stack, MediumFn &&medium, int src_slot = -1) {
-    BvhTrav s; bvh_begin(s, r, tmax, src_slot, sc.bvh_root);
+                                Stack &stack, MediumFn &&medium, int src_slot = -1, bool skip = false) {
+    BvhTrav s; bvh_begin(s, r, tmax, src_slot, skip ? RTC_BVH_EMPTY : sc.bvh_root);   // skip: this lane has nothing to trace (its hit is known)
     while (s.cur != RTC_BVH_EMPTY) bvh_trip_tab<KINDS>(sc, node_tab, leaf_tab, s, tmin, stack, medium);
     s.h.prim = s.h.slot >= 0 ? sc.leaf_prims[s.h.slot] : -1;
     return s.h;
 }
 template <int KINDS = RTC_KIND_ALL, typename Stack, typename MediumFn>
-RT_DEV HitS bvh_closest_hit(const SceneT<float> &sc, const RayT<float> &r, float tmin, float tmax, Stack &stack, MediumFn &&medium, int src_slot = -1) {
-    return bvh_closest_hit_tab<KINDS>(sc, reinterpret_cast<const float4 *>(sc.nodes), reinterpret_cast<const float4 *>(sc.bleaves), r, tmin, tmax, stack, medium, src_slot);
+RT_DEV HitS bvh_closest_hit(const SceneT<float> &sc, const RayT<float> &r, float tmin, float tmax, Stack &stack, MediumFn &&medium, int src_slot = -1, bool skip = false) {
+    return bvh_closest_hit_tab<KINDS>(sc, reinterpret_cast<const float4 *>(sc.nodes), reinterpret_cast<const float4 *>(sc.bleaves), r, tmin, tmax, stack, medium, src_slot, skip);
 }
 
 // Full hit record of the winning leaf: sphere_hit (:440-445) / rect_hit (:509-515), then the wrappers inside-out:

@@ -171,7 +171,7 @@ template <bool GENERAL> struct MediumSamplerT {
         const float inside = (t2 - t1) * ray_length;
         const float hit_distance = neg_inv_density * __logf(draw());
         if (hit_distance > inside) return false;
-        t_out = t1 + hit_distance * __builtin_amdgcn_rcpf(ray_length);
+        t_out = __builtin_fmaf(hit_distance, __builtin_amdgcn_rcpf(ray_length), t1);   // (explicit: k_wf_primary and k_wf_extend must agree bit for bit)
         return true;
     }
     __device__ bool operator()(int prim, float tmax, float &t_out) { return (*this)(prim, *ray, tmax, t_out); }
@@ -195,8 +195,8 @@ template <bool GENERAL> struct MediumSamplerT {
         const f3 oc = r.o - f3mk(d[0], d[1], d[2]);
         const float a = len2(r.d), inv_a = __builtin_amdgcn_rcpf(a);
         const float tc = -dot(oc, r.d) * inv_a;
-        const f3 l = oc + r.d * tc;
-        const float q = (d[3] * d[3] - len2(l)) * inv_a;
+        const f3 l = f3mk(__builtin_fmaf(r.d.x, tc, oc.x), __builtin_fmaf(r.d.y, tc, oc.y), __builtin_fmaf(r.d.z, tc, oc.z));
+        const float q = __builtin_fmaf(d[3], d[3], -len2(l)) * inv_a;
         if (q < 0.0f) return false;
         const float sq = __builtin_amdgcn_sqrtf(q);
         const float t1 = tc - sq, t2 = tc + sq;
@@ -373,16 +373,27 @@ RT_DEV int shade_hit(const SceneT<float> &sc, PathState &ps, const RecT<float> &
 // main.c:150-152 + camera.c:46-53 for sample s of a pixel: jitter from words 0, 1 of the camera block; a thin lens takes words 2, 3
 // for its disk sample and the shutter time a block of its own; a pinhole camera (every reference scene) leaves words 2, 3 unused, so
 // the shutter time is word 2 and a primary ray costs ONE Philox block.  Shared by the general megakernel and the wavefront kernels.
+// Every multiply-add below is an explicit fma and no product feeds a plain add: the compiler has no contraction left to decide, so every
+// kernel that inlines this function (init, the camera-ray pass, the tails that start a slot's next sample, the megakernel) makes the
+// SAME ray bit for bit -- the wavefront pipeline traces a camera ray in one kernel and shades its hit in another.
 RT_DEV RayT<float> primary_ray_f32(const CameraT<float> &cam, int width, int height, bool use_time, uint32_t seed_lo, uint32_t seed_hi,
                                    uint32_t pixel, int px, int py, uint32_t s) {
     const Rng4 c = rng_block(pixel, s, RT_TAG_CAMERA, seed_lo, seed_hi);
     const float u = ((float)px + c.x) / (float)(width - 1), v = ((float)py + c.y) / (float)(height - 1);
     float dx = 0.0f, dy = 0.0f, tm = cam.time0;
+    const float shutter = cam.time1 - cam.time0;
     if (cam.lens_radius > 0.0f) {
-        const float rr = __builtin_amdgcn_sqrtf(c.z); dx = rr * cos2pi(c.w); dy = rr * sin2pi(c.w);
-        if (use_time) tm = cam.time0 + (cam.time1 - cam.time0) * rng_block(pixel, s, RT_TAG_TIME, seed_lo, seed_hi).x;
-    } else if (use_time) tm = cam.time0 + (cam.time1 - cam.time0) * c.z;
-    return camera_ray<float>(cam, u, v, dx, dy, tm);
+        const float rr = __builtin_amdgcn_sqrtf(c.z) * cam.lens_radius; dx = rr * cos2pi(c.w); dy = rr * sin2pi(c.w);
+        if (use_time) tm = __builtin_fmaf(shutter, rng_block(pixel, s, RT_TAG_TIME, seed_lo, seed_hi).x, cam.time0);
+    } else if (use_time) tm = __builtin_fmaf(shutter, c.z, cam.time0);
+    RayT<float> r;                                                   // camera.c:46-53
+    const float ox = __builtin_fmaf(cam.v[0], dy, cam.u[0] * dx), oy = __builtin_fmaf(cam.v[1], dy, cam.u[1] * dx), oz = __builtin_fmaf(cam.v[2], dy, cam.u[2] * dx);   // lens offset
+    r.o = f3mk(cam.origin[0] + ox, cam.origin[1] + oy, cam.origin[2] + oz);
+    r.d = f3mk(__builtin_fmaf(cam.vertical[0], v, __builtin_fmaf(cam.horizontal[0], u, cam.llc[0])) - r.o.x,
+               __builtin_fmaf(cam.vertical[1], v, __builtin_fmaf(cam.horizontal[1], u, cam.llc[1])) - r.o.y,
+               __builtin_fmaf(cam.vertical[2], v, __builtin_fmaf(cam.horizontal[2], u, cam.llc[2])) - r.o.z);
+    r.time = tm;
+    return r;
 }
 
 RT_DEV f3 sky_color(f3 dir) {                                                          // 01 main.c:59-64

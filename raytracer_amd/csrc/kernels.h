@@ -56,6 +56,7 @@ struct WfBuffers {
                                       // the ray starts on (int bits), radiance sum of the slot; the pixel follows from the slot
     float2 *hit;                      // t, leaf slot (int bits; -1 = miss) written by extend
     unsigned char *key;               // per LIST position, written by extend: regrouping key of a hit parked for k_wf_shade (material type * 4 + texture type), RTC_WF_KEY_DONE otherwise
+    float2 *phit;                     // (phit_k x n_slots) closest hits of the camera rays of every slot's first phit_k samples, traced ahead by k_wf_primary
     int *active[2];                   // slot lists (ping-pong across compactions); -1 = hole
     unsigned *counters;               // 16 words, device-side control of the render (WF_*): live slots, compaction cursor, length and
                                       // buffer index of the current slot list -- the host enqueues a fixed schedule and never reads them
@@ -64,10 +65,13 @@ struct WfBuffers {
     int n_slots, slots_per_layer, layers;
     int quad;                         // slot <-> (pixel, layer) mapping of kernels_wf.hip slot_pixel
     WfDiv div_group, div_tiles_x;     // divisions of that mapping: by the slots of a layer group (4 layers when quad, else 1), by tiles_x
+    int phit_k;                       // 0: no camera rays traced ahead (every sample's first ray goes through the slot list)
+    WfDiv div_layers;                 // (sample - s_begin) / layers = which of the slot's samples
 };
 size_t wf_bytes_per_slot();
 size_t wf_stats_bytes();
 hipError_t launch_wf_init(const CameraT<float> &cam, const RenderParams &p, const WfBuffers &b, hipStream_t stream);
+hipError_t launch_wf_primary(const SceneT<float> &sc, const CameraT<float> &cam, const RenderParams &p, const WfBuffers &b, hipStream_t stream);
 // one bounce: extend (+ shade of the parked hits) over the current slot list, whose length and buffer index live in b.counters
 bool wf_lds_tables(const SceneT<float> &sc, size_t *lds_bytes);   // extend from LDS-resident node / leaf tables (small trees)?
 hipError_t launch_wf_bounce(const SceneT<float> &sc, const CameraT<float> &cam, const RenderParams &p, const WfBuffers &b, hipStream_t stream);

@@ -26,10 +26,7 @@
 
 namespace {
 
-#ifndef RT_WF_SUM_ATOMIC
-#define RT_WF_SUM_ATOMIC 0   // 1: no-return atomics instead of the read-modify-write; measured 1-3 % slower (round 3)
-#endif
-
+// (slot sums: no-return atomics instead of the read-modify-write measured 1-3 % slower, round 3)
 // live-slot counter: one atomic per wave that has something to report (a slot dies once per render)
 __device__ __forceinline__ void wave_count_sub(unsigned *__restrict__ counter, bool pred) {
     const unsigned long long m = __builtin_amdgcn_ballot_w64(pred);
@@ -69,6 +66,13 @@ __device__ __forceinline__ RayT<float> primary_ray(const CameraT<float> &cam, co
     return primary_ray_f32(cam, P.width, P.height, P.use_time != 0, P.seed_lo, P.seed_hi, pixel, px, py, s);   // same Philox blocks as the megakernel
 }
 
+// The closest hit of the camera ray of `sample` of this slot, if k_wf_primary has traced it ahead (the slot's samples 0 .. phit_k - 1)
+__device__ __forceinline__ bool wf_camera_hit(const RenderParams &P, const WfBuffers &B, int slot, int sample, float2 &ph) {
+    const int k = wf_div(sample - P.s_begin, B.div_layers);          // the slot's k-th sample
+    if (k >= B.phit_k) return false;
+    ph = B.phit[(size_t)k * (size_t)B.n_slots + (size_t)slot];
+    return true;
+}
 // ray.c:58-83 for ONE list entry whose closest hit is known, then the slot's bookkeeping: a finished path adds its radiance to the
 // slot's sum and the slot starts its next sample (or dies); otherwise the scattered ray is written back.  Returns true when the slot died.
 //   GENERAL = false: the hit's 48-byte shading record answers everything (leaf_shade: normal or centre, resolved colour, face flags) --
@@ -76,63 +80,80 @@ __device__ __forceinline__ RayT<float> primary_ray(const CameraT<float> &cam, co
 //   GENERAL = true : the leaf needs prims / chains / materials / textures (a texture to evaluate, a wrapper chain to replay): k_wf_shade.
 template <bool NOISE, bool GENERAL>
 __device__ __forceinline__ bool wf_shade_entry(const SceneT<float> &sc, const CameraT<float> &cam, const RenderParams &P, const WfBuffers &B, int slot,
-                                               int px, int py, const float4 &o, const float4 &d, const float4 &tm, float hit_t, int hslot, const SmallShade &sh) {
+                                               int px, int py, const float4 &o, const float4 &d, const float4 &tm, float hit_t, int hslot, SmallShade sh, unsigned char &key) {
     // sample, depth, leaf slot the ray starts on, pixel
     int4 m = make_int4((int)(__float_as_uint(tm.z) & 0xffffffu), (int)(__float_as_uint(tm.z) >> 24), __float_as_int(tm.w), py * P.width + px);
     PathState ps;
     ps.ray.o = f3mk(o.x, o.y, o.z); ps.ray.d = f3mk(d.x, d.y, d.z); ps.ray.time = o.w;
     ps.T = f3mk(d.w, tm.x, tm.y); ps.L = f3mk(0, 0, 0);
     const uint32_t pixel = (uint32_t)m.w;
-    int status;
-    if (hslot < 0) {                                                 // ray.c:56: background (01: sky gradient)
-        const f3 bg = P.integrator == 2 ? sky_color(ps.ray.d) : f3mk(sc.background[0], sc.background[1], sc.background[2]);
-        ps.L = ps.T * bg;
-        status = RT_TERMINATE;
-    } else {
-        const Rng4 xi = rng_block(pixel, (uint32_t)m.x, (uint32_t)m.y, P.seed_lo, P.seed_hi);
-        if (!GENERAL) {
-            RecT<float> rec; rec.u = 0; rec.v = 0; rec.mat = 0;
-            rec.p = ps.ray.o + ps.ray.d * hit_t;                      // ray_at, ray.c:8-11
-            f3 gv = f3mk(sh.g[0], sh.g[1], sh.g[2]);
-            if (sh.meta & RTC_SF_MOVING) gv = gv + f3mk(sh.pad[0], sh.pad[1], sh.pad[2]) * ps.ray.time;   // moving_sphere_center, hittable.c:455-458
-            const f3 n_out = (sh.meta & RTC_SF_SPHERE) ? (rec.p - gv) * sh.g[3] : gv;
-            bool front = dot(ps.ray.d, n_out) < 0.0f;                 // hit_record_set_facenormal, hittable.c:13-16
-            rec.n = front ? n_out : -n_out;
-            if (sh.meta & RTC_SF_FORCED_FRONT) front = true;          // translate/rotate re-face an already faced normal (F11)
-            if (sh.meta & RTC_SF_FLIP) front = !front;                // flip_face_hit, hittable.c:587-591
-            if (sh.meta & RTC_SF_MEDIUM) { rec.n = f3mk(1, 0, 0); front = true; }   // constant_medium_hit, hittable.c:578-582
-            rec.front = front;
-            MaterialT<float> mat; mat.type = (int)(sh.meta & 0xffu); mat.tex = -1; mat.albedo[0] = sh.rgb[0]; mat.albedo[1] = sh.rgb[1]; mat.albedo[2] = sh.rgb[2]; mat.param = sh.param;
-            status = shade_hit_mat<false>(sc, ps, rec, mat, true, P.integrator, P.light_weight, xi);
-            m.z = (sh.meta & RTC_SF_MEDIUM) ? -1 : hslot;
+    bool died = false, have_sum = false;
+    float4 s4 = make_float4(0, 0, 0, 0);
+    // One trip = one hit shaded.  A path that ends here starts the slot's next sample, and the closest hit of that sample's camera ray is
+    // already known (B.phit, k_wf_primary: the camera rays of a render are traced up front, in coherent waves of their own) -- so the
+    // loop shades it at once, and the slot goes back to the list with the SECOND ray of its new path: camera rays, a third of all rays,
+    // never enter the slot lists, where they would share waves with rays of every depth.
+    for (;;) {
+        int status;
+        ps.L = f3mk(0, 0, 0);
+        if (hslot < 0) {                                             // ray.c:56: background (01: sky gradient)
+            const f3 bg = P.integrator == 2 ? sky_color(ps.ray.d) : f3mk(sc.background[0], sc.background[1], sc.background[2]);
+            ps.L = ps.T * bg;
+            status = RT_TERMINATE;
         } else {
-            const PrimT<float> p = sc.prims[sc.leaf_prims[hslot]];
-            const MaterialT<float> &mat = sc.materials[p.mat];
-            const RecT<float> rec = resolve_hit<float>(sc, ps.ray, p, hit_t, material_needs_uv(sc, mat));
-            status = shade_hit<NOISE>(sc, ps, rec, P.integrator, P.light_weight, xi);
-            m.z = p.type == RTC_PRIM_MEDIUM ? -1 : hslot;
+            const Rng4 xi = rng_block(pixel, (uint32_t)m.x, (uint32_t)m.y, P.seed_lo, P.seed_hi);
+            if (!GENERAL) {
+                RecT<float> rec; rec.u = 0; rec.v = 0; rec.mat = 0;
+                rec.p = ps.ray.o + ps.ray.d * hit_t;                  // ray_at, ray.c:8-11
+                f3 gv = f3mk(sh.g[0], sh.g[1], sh.g[2]);
+                if (sh.meta & RTC_SF_MOVING) gv = gv + f3mk(sh.pad[0], sh.pad[1], sh.pad[2]) * ps.ray.time;   // moving_sphere_center, hittable.c:455-458
+                const f3 n_out = (sh.meta & RTC_SF_SPHERE) ? (rec.p - gv) * sh.g[3] : gv;
+                bool front = dot(ps.ray.d, n_out) < 0.0f;             // hit_record_set_facenormal, hittable.c:13-16
+                rec.n = front ? n_out : -n_out;
+                if (sh.meta & RTC_SF_FORCED_FRONT) front = true;      // translate/rotate re-face an already faced normal (F11)
+                if (sh.meta & RTC_SF_FLIP) front = !front;            // flip_face_hit, hittable.c:587-591
+                if (sh.meta & RTC_SF_MEDIUM) { rec.n = f3mk(1, 0, 0); front = true; }   // constant_medium_hit, hittable.c:578-582
+                rec.front = front;
+                MaterialT<float> mat; mat.type = (int)(sh.meta & 0xffu); mat.tex = -1; mat.albedo[0] = sh.rgb[0]; mat.albedo[1] = sh.rgb[1]; mat.albedo[2] = sh.rgb[2]; mat.param = sh.param;
+                status = shade_hit_mat<false>(sc, ps, rec, mat, true, P.integrator, P.light_weight, xi);
+                m.z = (sh.meta & RTC_SF_MEDIUM) ? -1 : hslot;
+            } else {
+                const PrimT<float> p = sc.prims[sc.leaf_prims[hslot]];
+                const MaterialT<float> &mat = sc.materials[p.mat];
+                const RecT<float> rec = resolve_hit<float>(sc, ps.ray, p, hit_t, material_needs_uv(sc, mat));
+                status = shade_hit<NOISE>(sc, ps, rec, P.integrator, P.light_weight, xi);
+                m.z = p.type == RTC_PRIM_MEDIUM ? -1 : hslot;
+            }
         }
-    }
-    ++m.y;
-    bool died = false;
-    if (status == RT_TERMINATE || m.y >= P.max_depth) {              // ray.c:52: depth exhausted adds nothing
+        ++m.y;
+        if (!(status == RT_TERMINATE || m.y >= P.max_depth)) break;  // the path goes on with the scattered ray (ray.c:52: depth exhausted adds nothing)
         const bool finite = (fabsf(ps.L.x) < 3.0e38f) && (fabsf(ps.L.y) < 3.0e38f) && (fabsf(ps.L.z) < 3.0e38f);
         if (finite && (ps.L.x != 0.0f || ps.L.y != 0.0f || ps.L.z != 0.0f)) {
-            // fire-and-forget adds (global_atomic_add_f32 without return): the wave does not wait for a load as a read-modify-write
-            // would make it; a slot is touched by ONE lane per launch and launches are ordered, so the sum is the same from run to run
-#if RT_WF_SUM_ATOMIC
-            float *sum = reinterpret_cast<float *>(B.sum + slot);
-            unsafeAtomicAdd(sum + 0, ps.L.x); unsafeAtomicAdd(sum + 1, ps.L.y); unsafeAtomicAdd(sum + 2, ps.L.z);
-#else
-            float4 s4 = B.sum[slot]; s4.x += ps.L.x; s4.y += ps.L.y; s4.z += ps.L.z; B.sum[slot] = s4;
-#endif
+            // a slot is touched by ONE lane per launch and launches are ordered, and its samples are added in sample order: the sum is the
+            // same from run to run (read once, written once per call, whatever the number of paths that end in it)
+            if (!have_sum) { s4 = B.sum[slot]; have_sum = true; }
+            s4.x += ps.L.x; s4.y += ps.L.y; s4.z += ps.L.z;
         }
         m.x += B.layers;                                             // this slot's next sample
-        if (m.x < P.s_end) {
-            ps.ray = primary_ray(cam, P, pixel, px, py, (uint32_t)m.x);
-            ps.T = f3mk(1, 1, 1); m.y = 0; m.z = -1;
-        } else died = true;
+        if (m.x >= P.s_end) { died = true; break; }
+        ps.ray = primary_ray(cam, P, pixel, px, py, (uint32_t)m.x);
+        ps.T = f3mk(1, 1, 1); m.y = 0; m.z = -1;
+        float2 ph;
+        if (!wf_camera_hit(P, B, slot, m.x, ph)) break;              // not traced ahead: the camera ray takes the ordinary route through extend
+        hit_t = ph.x; hslot = __float_as_int(ph.y);
+        if (!GENERAL) {
+            sh.meta = 0;
+            if (hslot >= 0) sh = sc.leaf_shade[hslot];
+            if (sh.meta & RTC_SF_GENERAL) {                          // k_wf_shade's: park the hit and its regrouping key next to the new path's state
+                B.hit[slot] = ph;
+                key = (unsigned char)((sh.meta >> 16) & 31u);
+                break;
+            }
+        } else if (hslot >= 0 && !(sc.leaf_shade[hslot].meta & RTC_SF_GENERAL)) break;   // a leaf that extend's tail shades from its record: left to the
+                                                                     // next extend launch (which takes the known hit and traces nothing), so that a hit is
+                                                                     // shaded by the same code whichever kernel started its path
     }
+    if (have_sum) B.sum[slot] = s4;
     if (!died) {
         B.ro[slot] = make_float4(ps.ray.o.x, ps.ray.o.y, ps.ray.o.z, ps.ray.time);
         B.rd[slot] = make_float4(ps.ray.d.x, ps.ray.d.y, ps.ray.d.z, ps.T.x);
@@ -166,7 +187,7 @@ __device__ __forceinline__ bool wf_extend_tail(const SceneT<float> &sc, const Ca
         key = (unsigned char)((sh.meta >> 16) & 31u);
         return false;
     }
-    return wf_shade_entry<false, false>(sc, cam, P, B, slot, px, py, o, d, tm, h.t, h.slot, sh);
+    return wf_shade_entry<false, false>(sc, cam, P, B, slot, px, py, o, d, tm, h.t, h.slot, sh, key);
 }
 
 __global__ void __launch_bounds__(256) k_wf_init(CameraT<float> cam, RenderParams P, WfBuffers B) {
@@ -207,6 +228,9 @@ template <> struct WfMedium<0> { using type = NoMedium32; };
 template <> struct WfMedium<1> { using type = MediumSphereOnly; };
 template <> struct WfMedium<2> { using type = MediumSampler; };
 constexpr int kWfStripes = 64;   // cache lines each statistic is striped over
+// (Round 3, measured and dropped: an XCD-aware block -> chunk mapping -- block b on chunk (b % 8) * (n / 8) + b / 8, so that each XCD's L2 sees one
+// contiguous eighth of the slot list, a band of the image -- was 1-4 % SLOWER on final, book1 and the 1M spheres: the bands differ in cost
+// (sky against ground) and the XCDs then finish at different times; the round-robin deal balances them.)
 #ifndef RT_WF_EXTEND_BLOCK
 #define RT_WF_EXTEND_BLOCK 64
 #endif
@@ -224,7 +248,7 @@ __global__ void __launch_bounds__(kWfExtendBlock) __attribute__((amdgpu_waves_pe
     const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
     const int slot = i < n_list ? B.active[cur][i] : -1;
     const bool live = slot >= 0;
-    bool died = false;
+    bool died = false, known = false;
     unsigned char key = (unsigned char)RTC_WF_KEY_DONE;
     if (live) {
         const float4 o = B.ro[slot], d = B.rd[slot];
@@ -239,14 +263,54 @@ __global__ void __launch_bounds__(kWfExtendBlock) __attribute__((amdgpu_waves_pe
             medium.k0 = P.seed_lo; medium.k1 = P.seed_hi; medium.draws = 0;
         }
         LdsStack stack(lds_stack + threadIdx.x, kWfExtendBlock, sc.bvh_stack);
-        const HitS h = bvh_closest_hit<KINDS>(sc, r, 0.001f, Mth<float>::inf(), stack, medium, src_slot);   // ray.c:56
+        float2 ph;                                                   // a camera ray (depth 0) whose hit k_wf_primary has found already: nothing to trace
+        known = (__float_as_uint(tm.z) >> 24) == 0u && wf_camera_hit(P, B, slot, (int)(__float_as_uint(tm.z) & 0xffffffu), ph);
+        HitS h = bvh_closest_hit<KINDS>(sc, r, 0.001f, Mth<float>::inf(), stack, medium, src_slot, known);   // ray.c:56
+        if (known) { h.t = ph.x; h.slot = __float_as_int(ph.y); }
         const WfArgs &t = wf_args_again(n_list);
         died = wf_extend_tail(t.sc, t.cam, t.P, t.B, slot, px, py, o, d, tm, h, key);
         if (died) t.B.active[cur][i] = -1;                           // stays in the list as a hole until the next compaction
     }
     if (sc.n_general && i < n_list) B.key[i] = key;                  // by LIST position: k_wf_shade scans them with coalesced reads
     wave_count_sub(B.counters + 0, died);
-    // statistics: two fire-and-forget atomics per block, striped over kWfStripes cache lines each
+    // statistics: two fire-and-forget atomics per block, striped over kWfStripes cache lines each (a known hit was counted by k_wf_primary)
+    const unsigned long long mask = __builtin_amdgcn_ballot_w64(live && !known);
+    const int rays = __syncthreads_count(live && !known);
+    const int waves = __syncthreads_count(mask != 0 && (threadIdx.x & 63) == 0);
+    if (threadIdx.x == 0 && rays) {
+        atomicAdd(B.stats + 8 * (1 + (blockIdx.x & (kWfStripes - 1))), (unsigned long long)rays);
+        atomicAdd(B.stats + 8 * (1 + kWfStripes + (blockIdx.x & (kWfStripes - 1))), (unsigned long long)waves);
+    }
+}
+
+// The camera rays of a render, traced ahead of its bounce schedule: entry (k, slot) = the closest hit of the slot's k-th sample, written
+// to B.phit as (t, leaf slot); an extend lane that finds a camera ray in its list (sample 0 from k_wf_init) takes the hit from there.  A wave = 64 consecutive slots = a 4x4-pixel
+// quadrant in four sample layers (slot_pixel), all on camera rays: its lanes walk nearly the same nodes, where the waves of the bounce
+// schedule mix rays of every depth (final scene: 14 G rays/s here against 6.6 G for the rays of the lists).  Same ray (primary_ray),
+// same traversal, same medium draws as extend would make for it at depth 0 -- the images are bit-identical to tracing them from the list.
+template <int MEDIA, int KINDS>
+__global__ void __launch_bounds__(kWfExtendBlock) __attribute__((amdgpu_waves_per_eu(MEDIA == 2 ? 6 : RT_WF_EXTEND_WAVES))) k_wf_primary(WfArgs a) {
+    const SceneT<float> &sc = a.sc; const RenderParams &P = a.P; const WfBuffers &B = a.B;
+    extern __shared__ int lds_stack[];                               // sc.bvh_stack entries per lane
+    const int slot = blockIdx.x * blockDim.x + threadIdx.x, k = (int)blockIdx.y;
+    bool live = false;
+    if (slot < B.n_slots) {
+        int px, py, layer; slot_pixel(P, B, slot, px, py, layer);
+        const int s = P.s_begin + layer + k * B.layers;
+        if (px < P.width && py < P.height && s < P.s_end) {
+            live = true;
+            const uint32_t pixel = (uint32_t)(py * P.width + px);
+            RayT<float> r = primary_ray(a.cam, P, pixel, px, py, (uint32_t)s);
+            typename WfMedium<MEDIA>::type medium;
+            if constexpr (MEDIA != 0) {
+                medium.sc = &sc; medium.ray = &r; medium.tmin = 0.001f; medium.pixel = pixel; medium.sample = (uint32_t)s; medium.bounce = 0;
+                medium.k0 = P.seed_lo; medium.k1 = P.seed_hi; medium.draws = 0;
+            }
+            LdsStack stack(lds_stack + threadIdx.x, kWfExtendBlock, sc.bvh_stack);
+            const HitS h = bvh_closest_hit<KINDS>(sc, r, 0.001f, Mth<float>::inf(), stack, medium, -1);   // ray.c:56
+            B.phit[(size_t)k * (size_t)B.n_slots + (size_t)slot] = make_float2(h.t, __int_as_float(h.slot));
+        }
+    }
     const unsigned long long mask = __builtin_amdgcn_ballot_w64(live);
     const int rays = __syncthreads_count(live);
     const int waves = __syncthreads_count(mask != 0 && (threadIdx.x & 63) == 0);
@@ -294,7 +358,7 @@ __global__ void __launch_bounds__(kWfLdsBlock) __attribute__((amdgpu_waves_per_e
         const unsigned i = chunk * 64u + lane;
         const int slot = i < n_list ? B.active[cur][i] : -1;
         const bool live = slot >= 0;
-        bool died = false;
+        bool died = false, known = false;
         unsigned char key = (unsigned char)RTC_WF_KEY_DONE;
         if (live) {
             const float4 o = B.ro[slot], d = B.rd[slot];
@@ -303,7 +367,10 @@ __global__ void __launch_bounds__(kWfLdsBlock) __attribute__((amdgpu_waves_per_e
             RayT<float> r; r.o = f3mk(o.x, o.y, o.z); r.d = f3mk(d.x, d.y, d.z); r.time = o.w;
             NoMedium32 medium;
             LdsStack16 stack(stacks + threadIdx.x, kWfLdsBlock, sc.bvh_stack);
-            const HitS h = bvh_closest_hit_tab<KINDS>(sc, node_tab, leaf_tab, r, 0.001f, Mth<float>::inf(), stack, medium, src_slot);   // ray.c:56
+            float2 ph;                                               // a camera ray whose hit is known (k_wf_extend)
+            known = (__float_as_uint(tm.z) >> 24) == 0u && wf_camera_hit(P, B, slot, (int)(__float_as_uint(tm.z) & 0xffffffu), ph);
+            HitS h = bvh_closest_hit_tab<KINDS>(sc, node_tab, leaf_tab, r, 0.001f, Mth<float>::inf(), stack, medium, src_slot, known);   // ray.c:56
+            if (known) { h.t = ph.x; h.slot = __float_as_int(ph.y); }
             const WfArgs &t = wf_args_again(chunk);
             int px, py, layer; slot_pixel(t.P, t.B, slot, px, py, layer);
             died = wf_extend_tail(t.sc, t.cam, t.P, t.B, slot, px, py, o, d, tm, h, key);
@@ -311,7 +378,7 @@ __global__ void __launch_bounds__(kWfLdsBlock) __attribute__((amdgpu_waves_per_e
         }
         if (sc.n_general && i < n_list) B.key[i] = key;
         wave_count_sub(B.counters + 0, died);
-        const unsigned long long mask = __builtin_amdgcn_ballot_w64(live);
+        const unsigned long long mask = __builtin_amdgcn_ballot_w64(live && !known);
         n_rays += (unsigned long long)__builtin_popcountll(mask); n_waves += mask != 0;
     }
     if (lane == 0 && n_rays) {
@@ -390,7 +457,8 @@ __global__ void __launch_bounds__(kWfShadeBlock) __attribute__((amdgpu_waves_per
                 int px, py, layer; slot_pixel(t.P, t.B, slot, px, py, layer);
                 const float2 hh = t.B.hit[slot];
                 SmallShade none; none.meta = 0;
-                died = wf_shade_entry<NOISE, true>(t.sc, t.cam, t.P, t.B, slot, px, py, o, d, tm, hh.x, __float_as_int(hh.y), none);
+                unsigned char no_key = 0;
+                died = wf_shade_entry<NOISE, true>(t.sc, t.cam, t.P, t.B, slot, px, py, o, d, tm, hh.x, __float_as_int(hh.y), none, no_key);
                 if (died) t.B.active[cur][sorted_index[tid]] = -1;   // stays in the list as a hole until the next compaction
             }
             wave_count_sub(B.counters + 0, died);
@@ -497,6 +565,18 @@ hipError_t launch_wf_bounce(const SceneT<float> &sc, const CameraT<float> &cam, 
     const dim3 sgrid(std::min((n_max + kWfShadeBlock - 1) / kWfShadeBlock, n_cus));   // persistent: one 1024-thread workgroup per CU
     if (sc.tex_kinds & (1 << RTC_TEX_NOISE)) hipLaunchKernelGGL(k_wf_shade<true>, sgrid, dim3(kWfShadeBlock), 0, stream, args);
     else hipLaunchKernelGGL(k_wf_shade<false>, sgrid, dim3(kWfShadeBlock), 0, stream, args);
+    return hipGetLastError();
+}
+// the camera rays of the first b.phit_k samples of every slot (b.phit); behind launch_wf_init on the part's stream, ahead of its first bounce
+hipError_t launch_wf_primary(const SceneT<float> &sc, const CameraT<float> &cam, const RenderParams &p, const WfBuffers &b, hipStream_t stream) {
+    if (b.phit_k <= 0 || b.n_slots <= 0 || p.max_depth <= 0) return hipSuccess;
+    const dim3 grid(((unsigned)b.n_slots + kWfExtendBlock - 1) / kWfExtendBlock, (unsigned)b.phit_k);
+    const size_t lds = (size_t)sc.bvh_stack * kWfExtendBlock * sizeof(int);
+    const WfArgs args{sc, cam, p, b};
+    if (sc.media_kind == 0 && sc.leaf_kinds == RTC_KIND_SPHERE) hipLaunchKernelGGL((k_wf_primary<0, RTC_KIND_SPHERE>), grid, dim3(kWfExtendBlock), lds, stream, args);
+    else if (sc.media_kind == 0) hipLaunchKernelGGL((k_wf_primary<0, RTC_KIND_ALL>), grid, dim3(kWfExtendBlock), lds, stream, args);
+    else if (sc.media_kind == 1) hipLaunchKernelGGL((k_wf_primary<1, RTC_KIND_ALL>), grid, dim3(kWfExtendBlock), lds, stream, args);
+    else hipLaunchKernelGGL((k_wf_primary<2, RTC_KIND_ALL>), grid, dim3(kWfExtendBlock), lds, stream, args);
     return hipGetLastError();
 }
 hipError_t launch_wf_compact(const WfBuffers &b, hipStream_t stream) {

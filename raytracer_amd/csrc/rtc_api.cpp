@@ -178,7 +178,7 @@ struct rtc_scene {
     DeviceTables<float> f32;
     DeviceTables<double> f64;
     DevBuf ray_counter;                        // wavefront only: striped statistics + queue counters, ordered across streams by wf_done like the pool
-    DevBuf wf_pool; size_t wf_slots_cap = 0;   // wavefront path-slot state, grown on demand
+    DevBuf wf_pool; size_t wf_pool_bytes = 0;   // wavefront path-slot state + camera-ray hits, grown on demand
     hipEvent_t wf_done = nullptr;              // end of the last wavefront render's final accumulate: the pool is shared by all streams
     hipStream_t wf_stream[4] = {nullptr, nullptr, nullptr, nullptr};   // streams of the parts a wavefront render is split into (part 0 runs on the caller's)
     hipEvent_t wf_fork = nullptr, wf_part_done[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -565,9 +565,14 @@ static int render_wavefront(rtc_scene *s, const CameraT<float> &camf, const Rend
     // the cap for experiments.
     long long max_slots = 32ll << 20;
     if (const char *e = std::getenv("RTC_WF_SLOTS")) { const long long v = std::atoll(e); if (v > 0) max_slots = v; }
-    struct Part { RenderParams p; long long layers, n_slots; WfBuffers b; long long iterations; };
+    // Camera rays traced ahead (k_wf_primary): the hits of the first phit_k samples of every slot, 8 bytes each, within a budget of 8 GB per
+    // render (32 M slots: 32 samples per slot; what lies beyond goes through the slot lists as before).  RTC_WF_PRIMARY=0: none (A/B, tests).
+    long long phit_budget = 8ll << 30;
+    if (const char *e = std::getenv("RTC_WF_PRIMARY")) { const long long v = std::atoll(e); phit_budget = v <= 0 ? 0 : (v == 1 ? phit_budget : v); }
+    struct Part { RenderParams p; long long layers, n_slots, phit_k; WfBuffers b; long long iterations; };
     Part part[RTC_WF_MAX_PARTS];
     long long total_slots = 0;
+    size_t phit_bytes = 0;
     for (int k = 0; k < n_parts; ++k) {
         Part &P = part[k];
         P.p = p_all;
@@ -580,8 +585,12 @@ static int render_wavefront(rtc_scene *s, const CameraT<float> &camf, const Rend
         if (layers > spp) layers = spp;
         if (layers < 1) layers = 1;
         P.layers = layers; P.n_slots = per_layer * layers;
-        P.iterations = ((spp + layers - 1) / layers) * (long long)(P.p.max_depth > 0 ? P.p.max_depth : 1);
+        const long long per_slot_samples = (spp + layers - 1) / layers;
+        P.iterations = per_slot_samples * (long long)(P.p.max_depth > 0 ? P.p.max_depth : 1);
+        P.phit_k = std::max<long long>(0, std::min<long long>(std::min<long long>(per_slot_samples, 65535), phit_budget / n_parts / (P.n_slots * 8)));
+        if (P.p.max_depth <= 0) P.phit_k = 0;
         total_slots += P.n_slots;
+        phit_bytes += (size_t)(P.phit_k * P.n_slots) * sizeof(float2);
     }
     if (total_slots > (1ll << 30)) return fail(RTC_ERR_ARG, "image too large for the wavefront path");
     const size_t per_slot = wf_bytes_per_slot();
@@ -589,10 +598,17 @@ static int render_wavefront(rtc_scene *s, const CameraT<float> &camf, const Rend
     // to overwrite (this call returns with that kernel enqueued, not finished): order this stream behind it.
     if (!s->wf_done) HIP_TRY(hipEventCreateWithFlags(&s->wf_done, hipEventDisableTiming));
     else HIP_TRY(hipStreamWaitEvent(stream, s->wf_done, 0));
-    if ((size_t)total_slots > s->wf_slots_cap) {
-        if (s->wf_pool.p) { HIP_TRY(hipEventSynchronize(s->wf_done)); HIP_TRY(hipStreamSynchronize(stream)); (void)hipFree(s->wf_pool.p); s->wf_pool.p = nullptr; s->wf_slots_cap = 0; }
-        if (hipMalloc(&s->wf_pool.p, (size_t)total_slots * per_slot + 256 * RTC_WF_MAX_PARTS) != hipSuccess) { s->wf_pool.p = nullptr; return fail(RTC_ERR_NOMEM, "wavefront path-slot state does not fit in device memory"); }
-        s->wf_slots_cap = (size_t)total_slots;
+    size_t pool_bytes = (size_t)total_slots * per_slot + phit_bytes + 512 * RTC_WF_MAX_PARTS;
+    if (pool_bytes > s->wf_pool_bytes) {
+        if (s->wf_pool.p) { HIP_TRY(hipEventSynchronize(s->wf_done)); HIP_TRY(hipStreamSynchronize(stream)); (void)hipFree(s->wf_pool.p); s->wf_pool.p = nullptr; s->wf_pool_bytes = 0; }
+        if (hipMalloc(&s->wf_pool.p, pool_bytes) != hipSuccess && phit_bytes) {   // no room for the camera-ray hits: render without them
+            (void)hipGetLastError();
+            for (int k = 0; k < n_parts; ++k) part[k].phit_k = 0;
+            pool_bytes -= phit_bytes; phit_bytes = 0; s->wf_pool.p = nullptr;
+            if (hipMalloc(&s->wf_pool.p, pool_bytes) != hipSuccess) s->wf_pool.p = nullptr;
+        }
+        if (!s->wf_pool.p) { (void)hipGetLastError(); return fail(RTC_ERR_NOMEM, "wavefront path-slot state does not fit in device memory"); }
+        s->wf_pool_bytes = pool_bytes;
     }
     for (int k = 1; k < n_parts; ++k)
         if (!s->wf_stream[k]) {
@@ -612,6 +628,8 @@ static int render_wavefront(rtc_scene *s, const CameraT<float> &camf, const Rend
         b.active[0] = (int *)base; base += n * sizeof(int);
         b.active[1] = (int *)base; base += n * sizeof(int);
         b.key = (unsigned char *)base; base += (n + 255) / 256 * 256;
+        b.phit = (float2 *)base; base += (size_t)part[k].phit_k * n * sizeof(float2);
+        b.phit_k = (int)part[k].phit_k; b.div_layers = wf_make_div((uint32_t)part[k].layers);
         char *ctl = (char *)s->ray_counter.p + (size_t)k * (wf_stats_bytes() + 64);
         b.stats = (unsigned long long *)ctl; b.stats_out = stats_out;
         b.counters = (unsigned *)(ctl + wf_stats_bytes());
@@ -625,6 +643,7 @@ static int render_wavefront(rtc_scene *s, const CameraT<float> &camf, const Rend
     if (n_parts > 1) HIP_TRY(hipEventRecord(s->wf_fork, stream));
     for (int k = 1; k < n_parts; ++k) { st[k] = s->wf_stream[k]; HIP_TRY(hipStreamWaitEvent(st[k], s->wf_fork, 0)); }
     for (int k = 0; k < n_parts; ++k) HIP_TRY(launch_wf_init(camf, part[k].p, part[k].b, st[k]));
+    for (int k = 0; k < n_parts; ++k) HIP_TRY(launch_wf_primary(s->f32.view, camf, part[k].p, part[k].b, st[k]));
     long long longest = 0;
     for (int k = 0; k < n_parts; ++k) longest = std::max(longest, part[k].iterations);
     for (long long it = 0; it < longest; ++it)                       // round robin, so that the parts' kernels reach the GPU interleaved

@@ -318,6 +318,30 @@ def test_wavefront_render_only_enqueues_and_its_parts_add_up(gpu, monkeypatch):
         sc.close()
 
 
+@pytest.mark.parametrize("name,W,H,spp", [("final", 384, 384, 48), ("book1", 480, 270, 40), ("box_field_smoke", 192, 192, 24), ("book2_random", 320, 180, 24),
+                                          ("final_earth", 320, 180, 24)])
+def test_camera_rays_traced_ahead_change_nothing(gpu, monkeypatch, name, W, H, spp):
+    """k_wf_primary traces the camera rays of a wavefront render up front, in coherent waves, and the kernel that ends a path shades the
+    next sample's known hit at once (kernels_wf.hip wf_shade_entry).  Same rays (primary_ray_f32 leaves the compiler no contraction to
+    decide), same traversal, same medium draws, same shading code per leaf, slot sums added in sample order: the accumulators are
+    BIT-IDENTICAL to tracing every camera ray from the slot list (RTC_WF_PRIMARY=0) and the ray counts are equal -- for media scenes
+    (sphere-bounded and general), the LDS-table extend (book1), textured leaves parked for k_wf_shade (book2_random: the checker ground and moving spheres; final_earth: an image texture), and when the
+    hit buffer only covers the first samples of each slot (a byte budget as RTC_WF_PRIMARY)."""
+    sc, cam, view = gpu.build_named_scene(name, aspect=W / H)
+    try:
+        st = gpu.Settings(W, H, spp, view.max_depth, view.integrator, seed=11, kernel=3)
+        out = []
+        for knob in ("0", "1", str(3 * 8 * (1 << 20)), "1"):         # off, on, room for ~3 samples of each of the >= 1M slots, on again
+            monkeypatch.setenv("RTC_WF_PRIMARY", knob)
+            acc, stats = sc.render(cam, st)
+            assert stats["kernel_used"] == 3 and stats["samples"] == W * H * spp
+            out.append((acc, stats["rays"]))
+        for acc, rays in out[1:]:
+            assert np.array_equal(acc, out[0][0]) and rays == out[0][1]
+    finally:
+        sc.close()
+
+
 @pytest.mark.parametrize("name,integrator,blk_tol", [("cornell", 0, 0.004), ("simple", 0, 0.004), ("cornell02", 1, 0.008)])
 def test_small_scene_kernel_agrees_with_general_kernel(gpu, name, integrator, blk_tol):
     """kernel=2 (packed leaves, LDS shading records, basis-free cosine sampling) and kernel=1 (general megakernel) are

@@ -399,72 +399,82 @@ constexpr int kWfShadeBlock = 1024;
 #ifndef RT_WF_SHADE_WAVES
 #define RT_WF_SHADE_WAVES 5      // resident waves per SIMD (96 VGPRs: no spills in either variant; 6 waves measured the same within 0.5 %)
 #endif
+// The scan takes FOUR keys per thread and trip (one dword load, one barrier per 4096 list entries; the next trip's keys are requested
+// before this trip's are looked at): with one key per thread and two barriers per 1024 entries the scan of a sparse list -- 2-3 % parked --
+// was most of this kernel's time.  The queue is a ring of 8192 entries (list position + key) in LDS.
 template <bool NOISE>
 __global__ void __launch_bounds__(kWfShadeBlock) __attribute__((amdgpu_waves_per_eu(RT_WF_SHADE_WAVES))) k_wf_shade(WfArgs a) {
-    constexpr unsigned N = kWfShadeBlock;
+    constexpr unsigned N = kWfShadeBlock, KPT = 4, QCAP = 8 * N;
     const WfBuffers &B = a.B;
     if (B.counters[WF_LIVE] == 0) return;
     const unsigned n_list = B.counters[WF_NLIST]; const int cur = (int)B.counters[WF_CUR];
-    __shared__ int q_slot[2 * N];
-    __shared__ unsigned q_index[2 * N];
-    __shared__ unsigned char q_key[2 * N];
+    __shared__ unsigned q_index[QCAP];
+    __shared__ unsigned char q_key[QCAP];
     __shared__ unsigned wave_count[N / 64], key_count[32], key_start[32];
-    __shared__ int sorted_slot[N];
     __shared__ unsigned sorted_index[N];
     const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    const unsigned n_chunks = (n_list + N - 1) / N;
-    unsigned q_n = 0;                                                // block-uniform: every thread keeps the same count
+    const unsigned n_chunks = (n_list + KPT * N - 1) / (KPT * N);
+    const unsigned *const key_words = reinterpret_cast<const unsigned *>(B.key);
+    const unsigned done4 = 0x01010101u * (unsigned)RTC_WF_KEY_DONE;
+    unsigned q_n = 0, q_head = 0;                                    // block-uniform: every thread keeps the same counts
+    auto keys_of = [&](unsigned chunk) { const unsigned w = chunk * N + tid; return w * KPT < n_list ? key_words[w] : done4; };   // (n_slots is a multiple of 64: a word is inside the array or not at all)
+    unsigned next = keys_of(blockIdx.x);
     for (unsigned c = blockIdx.x;; c += gridDim.x) {
         const bool flush = c >= n_chunks;                            // one trip past the end: shade what is still queued
         if (!flush) {
-            const unsigned i = c * N + tid;
-            const unsigned key = i < n_list ? B.key[i] : (unsigned)RTC_WF_KEY_DONE;   // DONE: shaded in extend's tail, or a hole of the list
-            const bool parked = key != (unsigned)RTC_WF_KEY_DONE;
-            const unsigned long long mask = __builtin_amdgcn_ballot_w64(parked);
-            if (lane == 0) wave_count[wave] = (unsigned)__builtin_popcountll(mask);
+            unsigned keys = next;
+            next = keys_of(c + gridDim.x);
+            const unsigned i0 = (c * N + tid) * KPT;
+            unsigned pos[KPT], n_wave = 0;
+            bool parked[KPT];
+#pragma unroll
+            for (unsigned j = 0; j < KPT; ++j) {                      // DONE: shaded in extend's tail, or a hole of the list; behind the list's end: stale
+                parked[j] = ((keys >> (8 * j)) & 0xffu) != (unsigned)RTC_WF_KEY_DONE && i0 + j < n_list;
+                const unsigned long long mask = __builtin_amdgcn_ballot_w64(parked[j]);
+                pos[j] = n_wave + (unsigned)__builtin_popcountll(mask & ((1ull << lane) - 1ull));
+                n_wave += (unsigned)__builtin_popcountll(mask);
+            }
+            if (lane == 0) wave_count[wave] = n_wave;
             __syncthreads();
             unsigned before = 0, total = 0;
             for (unsigned w = 0; w < N / 64; ++w) { const unsigned n = wave_count[w]; before += w < wave ? n : 0u; total += n; }
-            if (parked) {
-                const unsigned pos = q_n + before + (unsigned)__builtin_popcountll(mask & ((1ull << lane) - 1ull));
-                q_slot[pos] = B.active[cur][i]; q_index[pos] = i; q_key[pos] = (unsigned char)(key & 31u);
-            }
-            __syncthreads();
-            q_n += total;
+#pragma unroll
+            for (unsigned j = 0; j < KPT; ++j)
+                if (parked[j]) { const unsigned at = (q_head + q_n + before + pos[j]) & (QCAP - 1); q_index[at] = i0 + j; q_key[at] = (unsigned char)((keys >> (8 * j)) & 31u); }
+            q_n += total;                                            // <= (N - 1) + 4 N < QCAP
         }
-        if (q_n >= N || (flush && q_n > 0)) {
+        while (q_n >= N || (flush && q_n > 0)) {
             const unsigned take = q_n < N ? q_n : N;
             if (tid < 32) key_count[tid] = 0;
-            __syncthreads();
-            const unsigned key = tid < take ? q_key[tid] : 0u;
+            __syncthreads();                                         // (also: the queue entries written above are visible)
+            const unsigned at = (q_head + tid) & (QCAP - 1);
+            const unsigned key = tid < take ? q_key[at] : 0u;
+            const unsigned index = tid < take ? q_index[at] : 0u;
             const unsigned rank = tid < take ? atomicAdd(&key_count[key], 1u) : 0u;
             __syncthreads();
             if (tid == 0) { unsigned acc = 0; for (int k = 0; k < 32; ++k) { key_start[k] = acc; acc += key_count[k]; } }
             __syncthreads();
-            if (tid < take) { const unsigned pos = key_start[key] + rank; sorted_slot[pos] = q_slot[tid]; sorted_index[pos] = q_index[tid]; }
-            // what does not fit this round moves to the front of the queue (fewer than N entries)
-            const unsigned rest = q_n - take;
-            int r_slot = 0; unsigned r_index = 0; unsigned char r_key = 0;
-            if (tid < rest) { r_slot = q_slot[take + tid]; r_index = q_index[take + tid]; r_key = q_key[take + tid]; }
+            if (tid < take) sorted_index[key_start[key] + rank] = index;
+            q_head = (q_head + take) & (QCAP - 1); q_n -= take;
             __syncthreads();
-            if (tid < rest) { q_slot[tid] = r_slot; q_index[tid] = r_index; q_key[tid] = r_key; }
-            q_n = rest;
             bool died = false;
             if (tid < take) {
                 const WfArgs &t = wf_args_again(c);                  // scene, camera and render parameters: read here, not held across the scan
-                const int slot = sorted_slot[tid];
+                const unsigned i = sorted_index[tid];
+                const int slot = t.B.active[cur][i];
                 const float4 o = t.B.ro[slot], d = t.B.rd[slot], tm = t.B.tm[slot];
                 int px, py, layer; slot_pixel(t.P, t.B, slot, px, py, layer);
                 const float2 hh = t.B.hit[slot];
                 SmallShade none; none.meta = 0;
                 unsigned char no_key = 0;
                 died = wf_shade_entry<NOISE, true>(t.sc, t.cam, t.P, t.B, slot, px, py, o, d, tm, hh.x, __float_as_int(hh.y), none, no_key);
-                if (died) t.B.active[cur][sorted_index[tid]] = -1;   // stays in the list as a hole until the next compaction
+                if (died) t.B.active[cur][i] = -1;                   // stays in the list as a hole until the next compaction
             }
             wave_count_sub(B.counters + 0, died);
-            __syncthreads();                                         // sorted_* and the queue are free again
+            __syncthreads();                                         // sorted_index is free again
         }
         if (flush) break;
+        __syncthreads();                                             // wave_count is free again
     }
 }
 

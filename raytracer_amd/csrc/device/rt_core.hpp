@@ -227,14 +227,21 @@ struct HitS { float t; int prim, slot; };
 // One BLeaf against the ray: candidate parameter in [tmin, tmax] as sphere_t / rect_t accept it.  Written without early
 // returns: the leaf type is the only branch (usually wave-uniform), everything below it is selects, so the traversal
 // loop carries no nested exec masks.
+// Dot product with its contraction spelled out.  Under -ffp-contract=fast the compiler may fuse either product of x x' + y y' into the
+// FMA, and it does choose differently from one kernel to the next (seen in the listings: y first in one, x first in the other) -- the leaf
+// tests below must give the SAME t bit for bit in every kernel that inlines them (k_wf_extend, k_wf_extend_lds, k_wf_primary per lane
+// and per wave), so nothing in them is left to that choice: explicit FMAs, and no product that feeds a plain add.
+RT_DEV float dot_f(V3<float> a, V3<float> b) { return __builtin_fmaf(a.z, b.z, __builtin_fmaf(a.y, b.y, a.x * b.x)); }
+RT_DEV float len2_f(V3<float> a) { return dot_f(a, a); }
+RT_DEV V3<float> madd_f(V3<float> a, float k, V3<float> b) { return mk3<float>(__builtin_fmaf(a.x, k, b.x), __builtin_fmaf(a.y, k, b.y), __builtin_fmaf(a.z, k, b.z)); }   // a k + b
 RT_DEV bool sphere_roots_f32(V3<float> c, float rad, const RayT<float> &r, float tmin, float tmax, bool from_here, float &t) {
     // closest-approach form of line_sphere_intersection (see sphere_t<float>); a ray that starts on the sphere has the
     // roots {0, 2 tc} (sphere_leave_t)
     const V3<float> oc = r.o - c;
-    const float inv_a = __builtin_amdgcn_rcpf(len2(r.d));
-    const float tc = -dot(oc, r.d) * inv_a;
-    const V3<float> l = mk3<float>(__builtin_fmaf(r.d.x, tc, oc.x), __builtin_fmaf(r.d.y, tc, oc.y), __builtin_fmaf(r.d.z, tc, oc.z));
-    const float q = __builtin_fmaf(rad, rad, -len2(l)) * inv_a;
+    const float inv_a = __builtin_amdgcn_rcpf(len2_f(r.d));
+    const float tc = -dot_f(oc, r.d) * inv_a;
+    const V3<float> l = madd_f(r.d, tc, oc);
+    const float q = __builtin_fmaf(rad, rad, -len2_f(l)) * inv_a;
     const float sq = __builtin_amdgcn_sqrtf(fmaxf(q, 0.0f));
     const float t0 = from_here ? 2.0f * tc : tc - sq, t1 = tc + sq;
     const bool ok0 = (t0 >= tmin) & (t0 <= tmax), ok1 = (t1 >= tmin) & (t1 <= tmax) & !from_here;
@@ -268,9 +275,9 @@ RT_DEV bool bleaf_t(const BLeaf &lf, const RayT<float> &r, float tmin, float tma
     const uint32_t type = lf.meta & 3u;
     if ((KINDS & RTC_KIND_RECT) && type == RTC_PRIM_RECT) {
         const V3<float> N = mk3<float>(lf.d[0], lf.d[1], lf.d[2]), U = mk3<float>(lf.d[4], lf.d[5], lf.d[6]), V = mk3<float>(lf.d[8], lf.d[9], lf.d[10]);
-        const float tt = (lf.d[3] - dot(N, r.o)) * __builtin_amdgcn_rcpf(dot(N, r.d));
-        const V3<float> p = r.o + r.d * tt;
-        const float pa = dot(U, p), pb = dot(V, p);
+        const float tt = (lf.d[3] - dot_f(N, r.o)) * __builtin_amdgcn_rcpf(dot_f(N, r.d));
+        const V3<float> p = madd_f(r.d, tt, r.o);
+        const float pa = dot_f(U, p), pb = dot_f(V, p);
         t = tt;
         // a ray cannot re-hit the plane it leaves; a NaN t passes the range test like in the reference (F20)
         return !from_here & !(tt < tmin) & !(tt > tmax) & !(pa < lf.d[7]) & !(pa > lf.d[12]) & !(pb < lf.d[11]) & !(pb > lf.d[13]);
@@ -278,7 +285,7 @@ RT_DEV bool bleaf_t(const BLeaf &lf, const RayT<float> &r, float tmin, float tma
     if ((KINDS & RTC_KIND_SPHERE) && (type == RTC_PRIM_SPHERE || KINDS == RTC_KIND_SPHERE))
         return sphere_roots_f32(mk3<float>(lf.d[0], lf.d[1], lf.d[2]), lf.d[3], r, tmin, tmax, from_here, t);
     if ((KINDS & RTC_KIND_MSPHERE) && type == RTC_PRIM_MSPHERE)
-        return sphere_roots_f32(mk3<float>(lf.d[0] + lf.d[3] * r.time, lf.d[1] + lf.d[4] * r.time, lf.d[2] + lf.d[5] * r.time), lf.d[6], r, tmin, tmax, from_here, t);
+        return sphere_roots_f32(mk3<float>(__builtin_fmaf(lf.d[3], r.time, lf.d[0]), __builtin_fmaf(lf.d[4], r.time, lf.d[1]), __builtin_fmaf(lf.d[5], r.time, lf.d[2])), lf.d[6], r, tmin, tmax, from_here, t);
     return false;
 }
 // The traversal loop.  A lane stands on an inner node (cur >= 0) or on a leaf record (cur < 0); the nearer child is entered first,
@@ -302,14 +309,14 @@ RT_DEV void bvh_node_step(const BvhNodeCH &nd, BvhTrav &s, float tmin, Stack &st
     s.cur = first0 ? nd.child0 : nd.child1;
     if (!(h0 | h1)) s.cur = stack.pop();
 }
-template <int KINDS = RTC_KIND_ALL, typename Stack, typename MediumFn>
-RT_DEV void bvh_leaf_step(const SceneT<float> &sc, const BLeaf &lf, BvhTrav &s, float tmin, Stack &stack, MediumFn &&medium) {
-    const int v = ~s.cur, slot = v >> 3, rem = v & 7;
+// One leaf record (the one of slot `slot`) against the lane's ray: the closest hit so far is updated; returns the slots the record owns.
+template <int KINDS = RTC_KIND_ALL, typename MediumFn>
+RT_DEV int bvh_leaf_test(const SceneT<float> &sc, const BLeaf &lf, int slot, BvhTrav &s, float tmin, MediumFn &&medium) {
     int hit_slot = slot, width = 1;                              // a box record answers for six slots
     float t; bool hit;
     if ((lf.meta & 3u) == RTC_PRIM_MEDIUM) {
-        if (lf.meta & 0x80u) hit = medium.sphere_bounded(lf.d, s.r, s.h.t, t);
-        else hit = medium(sc.leaf_prims[slot], s.r, s.h.t, t);
+        if (lf.meta & 0x80u) hit = medium.sphere_bounded(lf.d, s.r, s.h.t, t, (uint32_t)slot);
+        else hit = medium(sc.leaf_prims[slot], s.r, s.h.t, t, (uint32_t)slot);
     }
     else if ((KINDS & RTC_KIND_BOX) && (lf.meta & RTC_LEAF_BOX)) {
         const unsigned sf = (unsigned)(s.src_slot - slot);
@@ -322,6 +329,12 @@ RT_DEV void bvh_leaf_step(const SceneT<float> &sc, const BLeaf &lf, BvhTrav &s, 
     // the slot -> id table is read there and once at the end, not on every accepted hit
     if (hit && t == s.h.t && s.h.slot >= 0) hit = sc.leaf_prims[hit_slot] >= sc.leaf_prims[s.h.slot];
     if (hit) { s.h.t = t; s.h.slot = hit_slot; }
+    return width;
+}
+template <int KINDS = RTC_KIND_ALL, typename Stack, typename MediumFn>
+RT_DEV void bvh_leaf_step(const SceneT<float> &sc, const BLeaf &lf, BvhTrav &s, float tmin, Stack &stack, MediumFn &&medium) {
+    const int v = ~s.cur, slot = v >> 3, rem = v & 7;
+    const int width = bvh_leaf_test<KINDS>(sc, lf, slot, s, tmin, medium);
     s.cur = rem ? ~(((slot + width) << 3) | (rem - 1)) : stack.pop();
 }
 // One loop, one step per trip: a lane either tests the two child boxes of an inner node or one leaf record, so lanes of a wave that
@@ -366,6 +379,51 @@ RT_DEV HitS bvh_closest_hit_tab(const SceneT<float> &sc, const float4 *node_tab,
 template <int KINDS = RTC_KIND_ALL, typename Stack, typename MediumFn>
 RT_DEV HitS bvh_closest_hit(const SceneT<float> &sc, const RayT<float> &r, float tmin, float tmax, Stack &stack, MediumFn &&medium, int src_slot = -1, bool skip = false) {
     return bvh_closest_hit_tab<KINDS>(sc, reinterpret_cast<const float4 *>(sc.nodes), reinterpret_cast<const float4 *>(sc.bleaves), r, tmin, tmax, stack, medium, src_slot, skip);
+}
+
+// The same closest hit with ONE traversal for the whole wave (camera rays: the 64 rays of a wave start at the eye and leave through a 4x4-pixel
+// window, k_wf_primary): the current node is wave-uniform, so a node or a leaf record is ONE scalar load (s_load_dwordx16) instead of 64
+// lanes fetching 64 bytes each, a trip runs the node arm OR one leaf kind (scalar branches: no arm runs for lanes that are elsewhere), and
+// the stack is one column of LDS per wave.  A child is entered when ANY lane's slab test passes (each lane tests against its own closest hit
+// so far), the child more lanes meet first goes first, and every lane tests every leaf record on the way: each lane ends with ITS closest
+// hit whatever the order (equal t: the later primitive wins, bvh_leaf_test; media draw by medium, not by visiting order) -- bit-identical
+// to bvh_closest_hit.  `on` = this lane has a ray (the others vote for nothing and test nothing).  wstack: sc.bvh_stack ints of LDS per wave.
+template <int KINDS = RTC_KIND_ALL, typename MediumFn>
+RT_DEV HitS bvh_closest_hit_wave(const SceneT<float> &sc, const RayT<float> &r, bool on, float tmin, float tmax, int *wstack, MediumFn &&medium) {
+    BvhTrav s; bvh_begin(s, r, tmax, -1, sc.bvh_root);
+    int cur = sc.bvh_root, sp = 0;                                   // wave-uniform
+    while (cur != RTC_BVH_EMPTY) {
+        if (cur >= 0) {
+            const BvhNodeCH nd = sc.nodes[cur];
+            float n0, n1;
+            const bool h0 = on & slab_f32(nd.c0, nd.h0, s.noi, s.inv, tmin, s.h.t, n0), h1 = on & slab_f32(nd.c1, nd.h1, s.noi, s.inv, tmin, s.h.t, n1);
+            const unsigned long long b0 = __builtin_amdgcn_ballot_w64(h0), b1 = __builtin_amdgcn_ballot_w64(h1);
+            if (b0 != 0 && b1 != 0) {
+                const unsigned long long near0 = __builtin_amdgcn_ballot_w64(h0 & (!h1 | (n0 <= n1)));   // lanes that would enter child 0 first
+                const bool first0 = 2 * __builtin_popcountll(near0) >= __builtin_popcountll(b0 | b1);
+                wstack[sp] = first0 ? nd.child1 : nd.child0; ++sp;
+                cur = first0 ? nd.child0 : nd.child1;
+            } else if (b0 != 0) cur = nd.child0;
+            else if (b1 != 0) cur = nd.child1;
+            else if (sp > 0) { --sp; cur = __builtin_amdgcn_readfirstlane(wstack[sp]); }
+            else cur = RTC_BVH_EMPTY;
+        } else {
+            const int v = ~cur;
+            int slot = v >> 3;
+            for (int rem = v & 7;; --rem) {
+                const BLeaf lf = sc.bleaves[slot];
+                int width = 1;
+                if (on) width = bvh_leaf_test<KINDS>(sc, lf, slot, s, tmin, medium);
+                width = (KINDS & RTC_KIND_BOX) && (lf.meta & RTC_LEAF_BOX) && (lf.meta & 3u) != RTC_PRIM_MEDIUM ? 6 : 1;   // (wave-uniform: from the record, not from a lane)
+                if (rem == 0) break;
+                slot += width;
+            }
+            if (sp > 0) { --sp; cur = __builtin_amdgcn_readfirstlane(wstack[sp]); }
+            else cur = RTC_BVH_EMPTY;
+        }
+    }
+    s.h.prim = -1;
+    return s.h;
 }
 
 // Full hit record of the winning leaf: sphere_hit (:440-445) / rect_hit (:509-515), then the wrappers inside-out:

@@ -142,40 +142,33 @@ RT_DEV bool material_needs_uv(const SceneT<float> &sc, const MaterialT<float> &m
 
 // ---- constant media in the closest-hit query (hittable.c:563-584) ----------------------------------------------------
 // The reference's constant_medium_hit is stochastic (it draws rand() for the free-flight distance), so the traversal calls
-// back into this functor for a medium leaf.  Draw k of a bounce comes from Philox block (pixel, sample, MEDIA|bounce|k/4).
+// back into this functor for a medium leaf.  The free-flight draw of medium `id` (its BVH leaf slot, or its primitive index in the list
+// scan) comes from the Philox block (pixel, sample, MEDIA | bounce | id): a function of the ray and the medium alone, NOT of the order in
+// which a traversal meets the media of a scene -- so two traversals that visit the tree in different orders (per-lane stacks in extend,
+// one wave-wide path for camera rays) find the same hit bit for bit.
 struct NoMedium32 {
     __device__ bool operator()(int, float, float &) const { return false; }
-    __device__ bool operator()(int, const RayT<float> &, float, float &) const { return false; }
-    __device__ bool sphere_bounded(const float *, const RayT<float> &, float, float &) const { return false; }
+    __device__ bool operator()(int, const RayT<float> &, float, float &, uint32_t) const { return false; }
+    __device__ bool sphere_bounded(const float *, const RayT<float> &, float, float &, uint32_t) const { return false; }
 };
-// GENERAL = false: only sphere-bounded media (their BLeaf carries the boundary); no boundary-list queries, and no cached
-// Philox block -- a ray meets few media, and the five registers decide the occupancy of the traversal kernel.
+// GENERAL = false: only sphere-bounded media (their BLeaf carries the boundary); no boundary-list queries.
 template <bool GENERAL> struct MediumSamplerT {
-    const SceneT<float> *sc; const RayT<float> *ray; float tmin; uint32_t pixel, sample, bounce, k0, k1; int draws;
-    Rng4 blk; int blk_id = -1;                                        // GENERAL: the Philox block the last draw came from
-    __device__ float draw() {
-        const int k = draws++;
-        if (!GENERAL) {
-            const Rng4 b = rng_block(pixel, sample, RT_TAG_MEDIA | (bounce << 8) | (uint32_t)(k >> 2), k0, k1);
-            return (k & 3) == 0 ? b.x : ((k & 3) == 1 ? b.y : ((k & 3) == 2 ? b.z : b.w));
-        }
-        if ((k >> 2) != blk_id) { blk_id = k >> 2; blk = rng_block(pixel, sample, RT_TAG_MEDIA | (bounce << 8) | (uint32_t)blk_id, k0, k1); }
-        return (k & 3) == 0 ? blk.x : ((k & 3) == 1 ? blk.y : ((k & 3) == 2 ? blk.z : blk.w));
-    }
+    const SceneT<float> *sc; const RayT<float> *ray; float tmin; uint32_t pixel, sample, bounce, k0, k1;
+    __device__ float draw(uint32_t id) const { return rng_block(pixel, sample, RT_TAG_MEDIA | ((bounce & 0x7fffu) << 16) | (id & 0xffffu), k0, k1).x; }
     // hittable.c:568-584 once the two boundary parameters are known; ray_length = |direction| in the medium's space
-    __device__ bool free_flight(float t1, float t2, float tmax, float ray_length, float neg_inv_density, float &t_out) {
+    __device__ bool free_flight(float t1, float t2, float tmax, float ray_length, float neg_inv_density, float &t_out, uint32_t id) const {
         if (t1 < tmin) t1 = tmin;
         if (t2 > tmax) t2 = tmax;
         if (t1 >= t2) return false;
         if (t1 < 0) t1 = 0;
         const float inside = (t2 - t1) * ray_length;
-        const float hit_distance = neg_inv_density * __logf(draw());
+        const float hit_distance = neg_inv_density * __logf(draw(id));
         if (hit_distance > inside) return false;
         t_out = __builtin_fmaf(hit_distance, __builtin_amdgcn_rcpf(ray_length), t1);   // (explicit: k_wf_primary and k_wf_extend must agree bit for bit)
         return true;
     }
-    __device__ bool operator()(int prim, float tmax, float &t_out) { return (*this)(prim, *ray, tmax, t_out); }
-    __device__ bool operator()(int prim, const RayT<float> &r, float tmax, float &t_out) {
+    __device__ bool operator()(int prim, float tmax, float &t_out) const { return (*this)(prim, *ray, tmax, t_out, (uint32_t)prim); }
+    __device__ bool operator()(int prim, const RayT<float> &r, float tmax, float &t_out, uint32_t id) const {
         if (!GENERAL) return false;
         const PrimT<float> &p = sc->prims[prim];
         NoMedium32 nv;
@@ -187,21 +180,21 @@ template <bool GENERAL> struct MediumSamplerT {
         const HitT<float> b = closest_hit_range<float>(*sc, sc->bprims, p.bnd_first, p.bnd_count, r, a.t + fmaxf(0.0001f, fabsf(a.t) * 4.8e-7f), inf, nv);
         if (b.prim < 0) return false;
         const RayT<float> rm = chain_enter(*sc, p.chain, r);
-        return free_flight(a.t, b.t, tmax, length(rm.d), p.d[0], t_out);
+        return free_flight(a.t, b.t, tmax, length(rm.d), p.d[0], t_out, id);
     }
     // boundary = one sphere, d = centre, radius, neg_inv_density in world space (rtc_tables.h BLeaf): the first boundary
     // query over (-inf, inf) returns the near root, the second one over (near + 0.0001, inf) the far root (sphere_t)
-    __device__ bool sphere_bounded(const float *d, const RayT<float> &r, float tmax, float &t_out) {
+    __device__ bool sphere_bounded(const float *d, const RayT<float> &r, float tmax, float &t_out, uint32_t id) const {
         const f3 oc = r.o - f3mk(d[0], d[1], d[2]);
-        const float a = len2(r.d), inv_a = __builtin_amdgcn_rcpf(a);
-        const float tc = -dot(oc, r.d) * inv_a;
-        const f3 l = f3mk(__builtin_fmaf(r.d.x, tc, oc.x), __builtin_fmaf(r.d.y, tc, oc.y), __builtin_fmaf(r.d.z, tc, oc.z));
-        const float q = __builtin_fmaf(d[3], d[3], -len2(l)) * inv_a;
+        const float a = len2_f(r.d), inv_a = __builtin_amdgcn_rcpf(a);       // (explicit FMAs: rt_core.hpp dot_f)
+        const float tc = -dot_f(oc, r.d) * inv_a;
+        const f3 l = madd_f(r.d, tc, oc);
+        const float q = __builtin_fmaf(d[3], d[3], -len2_f(l)) * inv_a;
         if (q < 0.0f) return false;
         const float sq = __builtin_amdgcn_sqrtf(q);
         const float t1 = tc - sq, t2 = tc + sq;
         if (t2 < t1 + fmaxf(0.0001f, fabsf(t1) * 4.8e-7f)) return false;
-        return free_flight(t1, t2, tmax, __builtin_amdgcn_sqrtf(a), d[4], t_out);
+        return free_flight(t1, t2, tmax, __builtin_amdgcn_sqrtf(a), d[4], t_out, id);
     }
 };
 using MediumSampler = MediumSamplerT<true>;

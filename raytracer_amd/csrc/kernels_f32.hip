@@ -52,7 +52,7 @@ __global__ void __launch_bounds__(256) k_pathtrace_mega(SceneT<float> sc, Camera
         if (__builtin_amdgcn_ballot_w64(alive) == 0) break;                // every lane of the wave is out of samples
         ++iters;                                                           // wave-uniform: bounce iterations of this wave
         if (alive) {
-            MediumSampler medium{&sc, &ps.ray, 0.001f, pixel, s_cur, (uint32_t)depth, P.seed_lo, P.seed_hi, 0};
+            MediumSampler medium{&sc, &ps.ray, 0.001f, pixel, s_cur, (uint32_t)depth, P.seed_lo, P.seed_hi};
             HitT<float> h; int hit_src;                                    // hit_src: what `src` must hold for the next ray
             if (BVH) {
                 LdsStack stack(lds_stack + threadIdx.x, 256, sc.bvh_stack);

@@ -39,7 +39,7 @@ __global__ void __launch_bounds__(256) k_ray_colors(SceneT<float> sc, RenderPara
         }
         if (__builtin_amdgcn_ballot_w64(alive) == 0) break;
         if (alive) {
-            MediumSampler medium{&sc, &ps.ray, 0.001f, i, s_cur, (uint32_t)depth, P.seed_lo, P.seed_hi, 0};
+            MediumSampler medium{&sc, &ps.ray, 0.001f, i, s_cur, (uint32_t)depth, P.seed_lo, P.seed_hi};
             HitT<float> h; int hit_src;
             if (BVH) {
                 LdsStack stack(lds_stack + threadIdx.x, 256, sc.bvh_stack);

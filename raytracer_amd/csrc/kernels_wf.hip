@@ -260,7 +260,7 @@ __global__ void __launch_bounds__(kWfExtendBlock) __attribute__((amdgpu_waves_pe
         if constexpr (MEDIA != 0) {
             const uint32_t sd = __float_as_uint(tm.z);
             medium.sc = &sc; medium.ray = &r; medium.tmin = 0.001f; medium.pixel = (uint32_t)(py * P.width + px); medium.sample = sd & 0xffffffu; medium.bounce = sd >> 24;
-            medium.k0 = P.seed_lo; medium.k1 = P.seed_hi; medium.draws = 0;
+            medium.k0 = P.seed_lo; medium.k1 = P.seed_hi;
         }
         LdsStack stack(lds_stack + threadIdx.x, kWfExtendBlock, sc.bvh_stack);
         float2 ph;                                                   // a camera ray (depth 0) whose hit k_wf_primary has found already: nothing to trace
@@ -288,7 +288,8 @@ __global__ void __launch_bounds__(kWfExtendBlock) __attribute__((amdgpu_waves_pe
 // quadrant in four sample layers (slot_pixel), all on camera rays: its lanes walk nearly the same nodes, where the waves of the bounce
 // schedule mix rays of every depth (final scene: 14 G rays/s here against 6.6 G for the rays of the lists).  Same ray (primary_ray),
 // same traversal, same medium draws as extend would make for it at depth 0 -- the images are bit-identical to tracing them from the list.
-template <int MEDIA, int KINDS>
+// WAVE = true: one traversal for the whole wave (rt_core.hpp bvh_closest_hit_wave: the node in SGPRs, one scalar load per node or leaf record).
+template <int MEDIA, int KINDS, bool WAVE>
 __global__ void __launch_bounds__(kWfExtendBlock) __attribute__((amdgpu_waves_per_eu(MEDIA == 2 ? 6 : RT_WF_EXTEND_WAVES))) k_wf_primary(WfArgs a) {
     const SceneT<float> &sc = a.sc; const RenderParams &P = a.P; const WfBuffers &B = a.B;
     extern __shared__ int lds_stack[];                               // sc.bvh_stack entries per lane
@@ -299,17 +300,34 @@ __global__ void __launch_bounds__(kWfExtendBlock) __attribute__((amdgpu_waves_pe
         const int s = P.s_begin + layer + k * B.layers;
         if (px < P.width && py < P.height && s < P.s_end) {
             live = true;
-            const uint32_t pixel = (uint32_t)(py * P.width + px);
-            RayT<float> r = primary_ray(a.cam, P, pixel, px, py, (uint32_t)s);
-            typename WfMedium<MEDIA>::type medium;
-            if constexpr (MEDIA != 0) {
-                medium.sc = &sc; medium.ray = &r; medium.tmin = 0.001f; medium.pixel = pixel; medium.sample = (uint32_t)s; medium.bounce = 0;
-                medium.k0 = P.seed_lo; medium.k1 = P.seed_hi; medium.draws = 0;
+            if constexpr (!WAVE) {
+                const uint32_t pixel = (uint32_t)(py * P.width + px);
+                RayT<float> r = primary_ray(a.cam, P, pixel, px, py, (uint32_t)s);
+                typename WfMedium<MEDIA>::type medium;
+                if constexpr (MEDIA != 0) {
+                    medium.sc = &sc; medium.ray = &r; medium.tmin = 0.001f; medium.pixel = pixel; medium.sample = (uint32_t)s; medium.bounce = 0;
+                    medium.k0 = P.seed_lo; medium.k1 = P.seed_hi;
+                }
+                LdsStack stack(lds_stack + threadIdx.x, kWfExtendBlock, sc.bvh_stack);
+                const HitS h = bvh_closest_hit<KINDS>(sc, r, 0.001f, Mth<float>::inf(), stack, medium, -1);   // ray.c:56
+                B.phit[(size_t)k * (size_t)B.n_slots + (size_t)slot] = make_float2(h.t, __int_as_float(h.slot));
             }
-            LdsStack stack(lds_stack + threadIdx.x, kWfExtendBlock, sc.bvh_stack);
-            const HitS h = bvh_closest_hit<KINDS>(sc, r, 0.001f, Mth<float>::inf(), stack, medium, -1);   // ray.c:56
-            B.phit[(size_t)k * (size_t)B.n_slots + (size_t)slot] = make_float2(h.t, __int_as_float(h.slot));
         }
+    }
+    if constexpr (WAVE) {                                            // every lane takes part in the wave's traversal; lanes without a ray only follow
+        static_assert(kWfExtendBlock == 64, "one wave per workgroup");
+        int px = 0, py = 0, layer = 0;
+        if (slot < B.n_slots) slot_pixel(P, B, slot, px, py, layer);
+        const int s = P.s_begin + layer + k * B.layers;
+        const uint32_t pixel = (uint32_t)(py * P.width + px);
+        RayT<float> r = primary_ray(a.cam, P, pixel, px, py, (uint32_t)s);
+        typename WfMedium<MEDIA>::type medium;
+        if constexpr (MEDIA != 0) {
+            medium.sc = &sc; medium.ray = &r; medium.tmin = 0.001f; medium.pixel = pixel; medium.sample = (uint32_t)s; medium.bounce = 0;
+            medium.k0 = P.seed_lo; medium.k1 = P.seed_hi;
+        }
+        const HitS h = bvh_closest_hit_wave<KINDS>(sc, r, live, 0.001f, Mth<float>::inf(), lds_stack, medium);   // ray.c:56
+        if (live) B.phit[(size_t)k * (size_t)B.n_slots + (size_t)slot] = make_float2(h.t, __int_as_float(h.slot));
     }
     const unsigned long long mask = __builtin_amdgcn_ballot_w64(live);
     const int rays = __syncthreads_count(live);
@@ -581,12 +599,17 @@ hipError_t launch_wf_bounce(const SceneT<float> &sc, const CameraT<float> &cam, 
 hipError_t launch_wf_primary(const SceneT<float> &sc, const CameraT<float> &cam, const RenderParams &p, const WfBuffers &b, hipStream_t stream) {
     if (b.phit_k <= 0 || b.n_slots <= 0 || p.max_depth <= 0) return hipSuccess;
     const dim3 grid(((unsigned)b.n_slots + kWfExtendBlock - 1) / kWfExtendBlock, (unsigned)b.phit_k);
-    const size_t lds = (size_t)sc.bvh_stack * kWfExtendBlock * sizeof(int);
     const WfArgs args{sc, cam, p, b};
-    if (sc.media_kind == 0 && sc.leaf_kinds == RTC_KIND_SPHERE) hipLaunchKernelGGL((k_wf_primary<0, RTC_KIND_SPHERE>), grid, dim3(kWfExtendBlock), lds, stream, args);
-    else if (sc.media_kind == 0) hipLaunchKernelGGL((k_wf_primary<0, RTC_KIND_ALL>), grid, dim3(kWfExtendBlock), lds, stream, args);
-    else if (sc.media_kind == 1) hipLaunchKernelGGL((k_wf_primary<1, RTC_KIND_ALL>), grid, dim3(kWfExtendBlock), lds, stream, args);
-    else hipLaunchKernelGGL((k_wf_primary<2, RTC_KIND_ALL>), grid, dim3(kWfExtendBlock), lds, stream, args);
+    bool wave = true;                                                // RTC_WF_PRIMARY_WAVE=0: per-lane traversal, as in extend (A/B, tests)
+    if (const char *e = std::getenv("RTC_WF_PRIMARY_WAVE")) wave = std::atoi(e) != 0;
+    const size_t lds = wave ? (size_t)sc.bvh_stack * sizeof(int) : (size_t)sc.bvh_stack * kWfExtendBlock * sizeof(int);
+#define RT_WF_PRIMARY(M, K) do { if (wave) hipLaunchKernelGGL((k_wf_primary<M, K, true>), grid, dim3(kWfExtendBlock), lds, stream, args); \
+                                 else hipLaunchKernelGGL((k_wf_primary<M, K, false>), grid, dim3(kWfExtendBlock), lds, stream, args); } while (0)
+    if (sc.media_kind == 0 && sc.leaf_kinds == RTC_KIND_SPHERE) RT_WF_PRIMARY(0, RTC_KIND_SPHERE);
+    else if (sc.media_kind == 0) RT_WF_PRIMARY(0, RTC_KIND_ALL);
+    else if (sc.media_kind == 1) RT_WF_PRIMARY(1, RTC_KIND_ALL);
+    else RT_WF_PRIMARY(2, RTC_KIND_ALL);
+#undef RT_WF_PRIMARY
     return hipGetLastError();
 }
 hipError_t launch_wf_compact(const WfBuffers &b, hipStream_t stream) {

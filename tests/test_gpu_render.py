@@ -321,9 +321,11 @@ def test_wavefront_render_only_enqueues_and_its_parts_add_up(gpu, monkeypatch):
 @pytest.mark.parametrize("name,W,H,spp", [("final", 384, 384, 48), ("book1", 480, 270, 40), ("box_field_smoke", 192, 192, 24), ("book2_random", 320, 180, 24),
                                           ("final_earth", 320, 180, 24)])
 def test_camera_rays_traced_ahead_change_nothing(gpu, monkeypatch, name, W, H, spp):
-    """k_wf_primary traces the camera rays of a wavefront render up front, in coherent waves, and the kernel that ends a path shades the
-    next sample's known hit at once (kernels_wf.hip wf_shade_entry).  Same rays (primary_ray_f32 leaves the compiler no contraction to
-    decide), same traversal, same medium draws, same shading code per leaf, slot sums added in sample order: the accumulators are
+    """k_wf_primary traces the camera rays of a wavefront render up front -- ONE traversal per wave, the node in scalar registers
+    (rt_core.hpp bvh_closest_hit_wave) -- and the kernel that ends a path shades the next sample's known hit at once (kernels_wf.hip
+    wf_shade_entry).  Same rays (primary_ray_f32 and the leaf tests leave the compiler no contraction to decide), a closest hit that does
+    not depend on the visiting order (ties by primitive id, media draws keyed by medium), same shading code per leaf, slot sums added in
+    sample order: the accumulators are
     BIT-IDENTICAL to tracing every camera ray from the slot list (RTC_WF_PRIMARY=0) and the ray counts are equal -- for media scenes
     (sphere-bounded and general), the LDS-table extend (book1), textured leaves parked for k_wf_shade (book2_random: the checker ground and moving spheres; final_earth: an image texture), and when the
     hit buffer only covers the first samples of each slot (a byte budget as RTC_WF_PRIMARY)."""
@@ -331,8 +333,10 @@ def test_camera_rays_traced_ahead_change_nothing(gpu, monkeypatch, name, W, H, s
     try:
         st = gpu.Settings(W, H, spp, view.max_depth, view.integrator, seed=11, kernel=3)
         out = []
-        for knob in ("0", "1", str(3 * 8 * (1 << 20)), "1"):         # off, on, room for ~3 samples of each of the >= 1M slots, on again
+        # off, on, room for ~3 samples of each of the >= 1M slots, on again, on with one traversal per LANE instead of per wave
+        for knob, wave in (("0", "1"), ("1", "1"), (str(3 * 8 * (1 << 20)), "1"), ("1", "1"), ("1", "0")):
             monkeypatch.setenv("RTC_WF_PRIMARY", knob)
+            monkeypatch.setenv("RTC_WF_PRIMARY_WAVE", wave)
             acc, stats = sc.render(cam, st)
             assert stats["kernel_used"] == 3 and stats["samples"] == W * H * spp
             out.append((acc, stats["rays"]))

@@ -54,15 +54,16 @@ PEAK_L2_GBS = 34500.0             # MI355X_MICROARCH.md: 8 x 4 MiB L2, ~34.5 TB/
 # BVH scenes (wavefront kernels).  Per ray: node steps and leaf steps of the production two-child tree, counted by round 2's step-probe
 # builds (the probes left the product sources in round 3, the tree and the traversal order have not changed since).
 #   bytes/ray = (node steps + leaf steps) x 64 B (a node and a traversal leaf are both 64 B) + 101 B of path-slot state per
-#               bounce (extend with its shading tail: list entry 4 R, state 48 R + 48 W, key 1 W; round 2's separate shade stage
-#               made it 166 B)
+#               bounce for a ray of the slot lists (extend with its shading tail: list entry 4 R, state 48 R + 48 W, key 1 W; round
+#               2's separate shade stage made it 166 B) or 16 B for a camera ray (k_wf_primary writes its hit, the tail that starts
+#               the sample reads it: the camera rays -- 1 / rays_per_sample of all rays -- never pass through the lists)
 #   FLOP/ray  = node steps x 30 (two aabb slab tests, aabb.c:33-63 at 15 each) + leaf steps x leaf test (sphere 26,
 #               hittable.c:406-429; rect 6; a box record's slab ~18: scene average) + everything that is not traversal, from
 #               the instrumented oracle run of tests/flop_model.py on the same scene (hit records, media, textures, materials,
 #               camera): final 128.1, final_earth 119.4, book1 32.8
 # Which roof: final / final_earth / book1 keep their trees (<= 285 KB) in L2 and are bound by VALU issue under divergence
-# (profiles/r03a/final: extend active-lane 0.24, wait 0.55) -> "valu"; the 1M-sphere tree (105 MB) is served by L2 + Infinity Cache
-# (profiles/r03a/million: TCC hit rate 0.55) -> "l2", with the L2 requests counted by rocprofv3 beside the algorithmic bytes.
+# (profiles/r03d/final: extend active-lane 0.19, wait 0.59) -> "valu"; the 1M-sphere tree (105 MB) is served by L2 + Infinity Cache
+# (profiles/r03d/million: TCC hit rate 0.61) -> "l2", with the L2 requests counted by rocprofv3 beside the algorithmic bytes.
 SCENE_MODEL = {
     "final":       dict(node_steps=10.4, leaf_steps=3.3, leaf_flop=22, other_flop=128.1, bound="valu"),
     "final_earth": dict(node_steps=10.0, leaf_steps=2.7, leaf_flop=22, other_flop=119.4, bound="valu"),
@@ -70,17 +71,20 @@ SCENE_MODEL = {
     "million":     dict(node_steps=23.6, leaf_steps=2.7, leaf_flop=26, other_flop=32.8, bound="l2"),
 }
 for _m in SCENE_MODEL.values():
-    _m["bytes_per_ray"] = (_m["node_steps"] + _m["leaf_steps"]) * 64 + 101
+    _m["bytes_per_ray"] = (_m["node_steps"] + _m["leaf_steps"]) * 64 + 101   # a ray of the slot lists; scene_roofline() prices the camera rays at 16 B
     _m["flop_per_ray"] = _m["node_steps"] * 30 + _m["leaf_steps"] * _m["leaf_flop"] + _m["other_flop"]
 SCENE_BYTES = {k: v["bytes_per_ray"] for k, v in SCENE_MODEL.items()}
 WORKLOADS = {"final": "02_AdvancedTracer final scene", "final_earth": "02_AdvancedTracer final scene + earth-map globe",
              "book1": "01_BasicTracer Book-1 random spheres", "million": "synthetic 1,000,004-sphere scene"}
 
 
-def scene_roofline(scene, rays_per_launch, k_ms):
+def scene_roofline(scene, rays_per_launch, k_ms, rays_per_sample=None):
     """roofline object of a BVH scene: FP32 VALU roof where the kernels are issue bound, aggregate L2 where they wait for node fetches."""
-    m = SCENE_MODEL[scene]
-    common = {"kernel": "k_wf_extend (traversal + shading tail) + k_wf_shade (textured hits)", "kernel_ms": k_ms, "rays_per_launch": rays_per_launch,
+    m = dict(SCENE_MODEL[scene])
+    if rays_per_sample:                                              # camera rays: 16 B of hit buffer instead of 101 B of slot state
+        m["bytes_per_ray"] = (m["node_steps"] + m["leaf_steps"]) * 64 + (101 * (rays_per_sample - 1) + 16) / rays_per_sample
+    common = {"kernel": "k_wf_primary (camera rays, one traversal per wave) + k_wf_extend (traversal + shading tail) + k_wf_shade (textured hits)",
+              "kernel_ms": k_ms, "rays_per_launch": rays_per_launch,
               "algorithmic_flop_per_ray": m["flop_per_ray"], "algorithmic_bytes_per_ray": m["bytes_per_ray"],
               "node_steps_per_ray": m["node_steps"], "leaf_steps_per_ray": m["leaf_steps"]}
     # second wall of the traversal (DESIGN.md 3.2, profiles/r02d): 64-byte node / leaf records fetched at random; the gather loop of
@@ -97,12 +101,12 @@ def scene_roofline(scene, rays_per_launch, k_ms):
 
 
 def measured_l2_requests(scene):
-    """TCC_HIT + TCC_MISS of k_wf_extend per launch from the committed rocprofv3 pass of this scene (profiles/r03a), or None."""
+    """TCC_HIT + TCC_MISS of k_wf_extend per launch from the committed rocprofv3 pass of this scene (profiles/r03d), or None."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r03a", scene, "summary.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r03d", scene, "summary.json")) as f:
             s = json.load(f)
         p = s["pmc_per_launch"]
-        return {"profile": "r03a/" + scene, "kernel": s.get("kernel"), "tcc_hit_per_launch": p["TCC_HIT_sum"], "tcc_miss_per_launch": p["TCC_MISS_sum"],
+        return {"profile": "r03d/" + scene, "kernel": s.get("kernel"), "tcc_hit_per_launch": p["TCC_HIT_sum"], "tcc_miss_per_launch": p["TCC_MISS_sum"],
                 "hit_rate": p["TCC_HIT_sum"] / (p["TCC_HIT_sum"] + p["TCC_MISS_sum"]), "kernel_ms": s.get("avg_ms")}
     except (OSError, KeyError, ValueError, ZeroDivisionError):
         return None
@@ -178,7 +182,7 @@ def other_config(scene, W, H, spp, dev):
     out = {"workload": f"{WORKLOADS[scene]}, {W}x{H}, {spp} spp, depth {view.max_depth}", "scene_build_s": round(build_s, 3),
            "ms": st["kernel_ms"], "ms_all": [round(r["kernel_ms"], 3) for r in runs], "renders": len(runs), "statistic": "median",
            "msamples_per_s": st["samples"] / st["kernel_ms"] * 1e-3, "mrays_per_s": st["rays"] / st["kernel_ms"] * 1e-3,
-           "rays_per_sample": st["rays"] / st["samples"], "roofline": scene_roofline(scene, st["rays"], st["kernel_ms"])}
+           "rays_per_sample": st["rays"] / st["samples"], "roofline": scene_roofline(scene, st["rays"], st["kernel_ms"], st["rays"] / st["samples"])}
     sc.close()
     return out
 

@@ -554,7 +554,9 @@ static int render_wavefront(rtc_scene *s, const CameraT<float> &camf, const Rend
     const long long per_layer = (long long)p_all.n_tiles * 64;
     // parts of at least ~5 M path slots each: smaller ones lose more to their launches than the overlap gains (final 512^2 x 256 spp, 8.4 M slots:
     // one part 33.9 ms, three 37.4; 1024^2, 32 M slots: 116 against 94)
-    const long long slots_wanted = std::min<long long>((long long)((spp_all + 7) / 8) * per_layer, 32ll << 20);
+    int sps = 8;                                                     // samples per slot aimed at
+    if (const char *e = std::getenv("RTC_WF_SPS")) { const int v = std::atoi(e); if (v >= 1) sps = v; }   // A/B knob
+    const long long slots_wanted = std::min<long long>((long long)((spp_all + sps - 1) / sps) * per_layer, 32ll << 20);
     int n_parts = (int)std::max<long long>(1, std::min<long long>(3, slots_wanted / (5ll << 20)));
     if (const char *e = std::getenv("RTC_WF_PARTS")) { const int v = std::atoi(e); if (v >= 1 && v <= RTC_WF_MAX_PARTS) n_parts = v; }   // A/B knob
     if (n_parts > spp_all) n_parts = spp_all;
@@ -579,7 +581,7 @@ static int render_wavefront(rtc_scene *s, const CameraT<float> &camf, const Rend
         P.p.s_begin = p_all.s_begin + (int)((long long)spp_all * k / n_parts);
         P.p.s_end = p_all.s_begin + (int)((long long)spp_all * (k + 1) / n_parts);
         const int spp = P.p.s_end - P.p.s_begin;
-        long long layers = (spp + 7) / 8;
+        long long layers = (spp + sps - 1) / sps;
         if (layers * per_layer > max_slots / n_parts) layers = max_slots / n_parts / per_layer;
         if (layers * per_layer < (1ll << 20) / n_parts) layers = ((1ll << 20) / n_parts + per_layer - 1) / per_layer;   // small images: at least 1M slots in all
         if (layers > spp) layers = spp;

@@ -61,7 +61,7 @@ texture *texture_checker_init(texture *odd, texture *even);
 texture *texture_checker_init_c(color odd, color even);
 texture *texture_noise_init_scaled(double sc); /* builds the perlin tables with rand(), perlin.c:67-75 */
 texture *texture_noise_init(void);
-texture *texture_image_init(char *filename);   /* baseline JPEG or binary PPM (P6); NULL + message on failure like texture.c:67 */
+texture *texture_image_init(char *filename);   /* JPEG (baseline, progressive), PNG, BMP, binary PGM / PPM; NULL + message on failure like texture.c:67 */
 texture *texture_image_init_rgb(const unsigned char *rgb, int width, int height); /* extension: decoded pixels */
 void     texture_free(texture *t);              /* texture.h:65; also clears the registry slot (the reference leaves it dangling) */
 void     textures_free_all(void);

@@ -13,8 +13,11 @@
  *   - YCbCr -> RGB in 20-bit fixed point with 12-bit coefficients, the Cb term of G truncated to 16 bits before the sum
  *     (stb_image.h:3556-3582); component ids "RGB" (or Adobe transform 0 without JFIF) mean no conversion.
  *   - 1 or 3 components, sampling factors 1 or 2, restart intervals.
- * Progressive (SOF2), arithmetic-coded, 12-bit and CMYK files are refused (return 0), like any file that is cut short
- * (stb decodes progressive files; no reference scene has one).
+ *   - progressive files (SOF2: spectral selection and successive approximation, T.81 annex G): the scans fill 16-bit coefficient
+ *     planes -- DC first / refinement, AC first / refinement with end-of-band runs -- which are dequantised (the product wraps to
+ *     16 bits as in stb) and transformed once the last scan is in; from there on the path is the baseline one.
+ * Arithmetic-coded, lossless, 12-bit and CMYK files and baseline files of more than one scan are refused (return 0), like any
+ * file that is cut short.
  * tests/test_host_api.py: equal to the reference's own stbi_load output on every sample of images/earthmap.jpg and of
  * 4:2:0 / 4:2:2 / 4:4:0 / grey / restart-interval files (tests/golden/jpeg_cases.npz, made by the compiled reference).
  */
@@ -25,7 +28,7 @@
 #include "scene_internal.h"
 
 typedef struct { unsigned char bits[17]; unsigned char vals[256]; int mincode[17], maxcode[18], valptr[17]; int present; } huff_table;
-typedef struct { int id, h, v, tq, td, ta; int w, hgt, stride; unsigned char *plane; int pred; } component;
+typedef struct { int id, h, v, tq, td, ta; int w, hgt, stride; unsigned char *plane; int pred; short *coef; int blocks_w, blocks_h; } component;
 typedef struct {
     const unsigned char *p, *end;
     unsigned int bitbuf; int bitcnt; int marker; /* marker hit inside entropy data (0 = none) */
@@ -139,6 +142,114 @@ static const unsigned char *upsample_row(unsigned char *out, const unsigned char
     for (int i = 0; i < w; i++) for (int j = 0; j < hs; j++) out[i * hs + j] = near[i];   /* other factors: nearest */
     return out;
 }
+/* planes -> RGB8, row by row: upsample every component to full width, then convert (stb_image.h:3794-3850); NULL when out of memory */
+static unsigned char *planes_to_rgb(component *comp, int ncomp, int W, int H, int hmax, int vmax, int is_rgb) {
+    unsigned char *rgb = (unsigned char *)malloc((size_t)W * H * 3);
+    if (!rgb) return NULL;
+    unsigned char *line[3] = {NULL, NULL, NULL};
+    const unsigned char *row0[3], *row1[3]; int ystep[3], ypos[3], hs[3], vs[3], wl[3];
+    int alloc_ok = 1;
+    for (int c = 0; c < ncomp; c++) {
+        line[c] = (unsigned char *)malloc((size_t)W + 3 + 8);
+        if (!line[c]) alloc_ok = 0;
+        hs[c] = hmax / comp[c].h; vs[c] = vmax / comp[c].v; ystep[c] = vs[c] >> 1; ypos[c] = 0; wl[c] = (W + hs[c] - 1) / hs[c];
+        row0[c] = row1[c] = comp[c].plane;
+    }
+    for (int y = 0; y < H && alloc_ok; y++) {
+        const unsigned char *cur[3] = {NULL, NULL, NULL};
+        for (int c = 0; c < ncomp; c++) {
+            const int bot = ystep[c] >= (vs[c] >> 1);
+            cur[c] = upsample_row(line[c], bot ? row1[c] : row0[c], bot ? row0[c] : row1[c], wl[c], hs[c], vs[c]);
+            if (++ystep[c] >= vs[c]) { ystep[c] = 0; row0[c] = row1[c]; if (++ypos[c] < comp[c].hgt) row1[c] += comp[c].stride; }
+        }
+        unsigned char *o = rgb + (size_t)y * W * 3;
+        for (int x = 0; x < W; x++, o += 3) {
+            if (ncomp == 1) { o[0] = o[1] = o[2] = cur[0][x]; continue; }
+            if (is_rgb) { o[0] = cur[0][x]; o[1] = cur[1][x]; o[2] = cur[2][x]; continue; }
+            const int yf = (cur[0][x] << 20) + (1 << 19), cb = cur[1][x] - 128, cr = cur[2][x] - 128;
+            /* JFIF: R = Y + 1.402 Cr, G = Y - 0.71414 Cr - 0.34414 Cb, B = Y + 1.772 Cb; coefficients round(c * 4096) << 8;
+             * the Cb term of G loses its low 16 bits before it is added (stb's SIMD-compatible form) */
+            o[0] = clamp8((yf + cr * 1470208) >> 20);
+            o[1] = clamp8((int)(yf + cr * -748800 + (int)((unsigned)(cb * -360960) & 0xffff0000u)) >> 20);
+            o[2] = clamp8((yf + cb * 1858048) >> 20);
+        }
+    }
+    for (int c = 0; c < 3; c++) free(line[c]);
+    if (!alloc_ok) { free(rgb); return NULL; }
+    return rgb;
+}
+
+/* ---- progressive scans (T.81 annex G) ------------------------------------------------------------------------------------------ */
+typedef struct { int ss, se, ah, al, eob_run; } prog_scan;
+/* one block of a DC scan: the first pass leaves the prediction shifted left by Al, a refinement pass adds one bit */
+static int prog_dc(bitreader *br, const huff_table *t, component *c, short *d, const prog_scan *ps) {
+    if (ps->ah == 0) {
+        const int n = huff_decode(br, t);
+        if (n < 0 || n > 15) return 0;
+        c->pred += n ? extend(get_bits(br, n), n) : 0;
+        d[0] = (short)(c->pred * (1 << ps->al));
+    } else if (next_bit(br)) d[0] = (short)(d[0] + (short)(1 << ps->al));
+    return 1;
+}
+/* one block of an AC scan over the band ss..se */
+static int prog_ac(bitreader *br, const huff_table *t, short *d, prog_scan *ps) {
+    if (ps->ah == 0) {                                               /* first pass: values shifted left by Al, bands of zero blocks as EOB runs */
+        if (ps->eob_run) { --ps->eob_run; return 1; }
+        int k = ps->ss;
+        do {
+            const int rs = huff_decode(br, t);
+            if (rs < 0) return 0;
+            const int s = rs & 15, r = rs >> 4;
+            if (s == 0) {
+                if (r < 15) { ps->eob_run = 1 << r; if (r) ps->eob_run += get_bits(br, r); --ps->eob_run; break; }
+                k += 16;
+            } else {
+                k += r;
+                if (k > 63) return 0;
+                d[kZigzag[k++]] = (short)(extend(get_bits(br, s), s) * (1 << ps->al));
+            }
+        } while (k <= ps->se);
+        return 1;
+    }
+    const short bit = (short)(1 << ps->al);                          /* refinement: one more bit for the coefficients that are set, new +-1 ones between them */
+    if (ps->eob_run) {
+        --ps->eob_run;
+        for (int k = ps->ss; k <= ps->se; ++k) {
+            short *p = d + kZigzag[k];
+            if (*p != 0 && next_bit(br) && (*p & bit) == 0) *p = (short)(*p > 0 ? *p + bit : *p - bit);
+        }
+        return 1;
+    }
+    int k = ps->ss;
+    do {
+        const int rs = huff_decode(br, t);
+        if (rs < 0) return 0;
+        int s = rs & 15, r = rs >> 4;
+        if (s == 0) {
+            if (r < 15) { ps->eob_run = (1 << r) - 1; if (r) ps->eob_run += get_bits(br, r); r = 64; }   /* the rest of this band, then eob_run more blocks */
+        } else {
+            if (s != 1) return 0;
+            s = next_bit(br) ? bit : -bit;
+        }
+        while (k <= ps->se) {
+            short *p = d + kZigzag[k++];
+            if (*p != 0) { if (next_bit(br) && (*p & bit) == 0) *p = (short)(*p > 0 ? *p + bit : *p - bit); }
+            else { if (r == 0) { *p = (short)s; break; } --r; }
+        }
+    } while (k <= ps->se);
+    return 1;
+}
+/* RSTn between two restart intervals: realign, reset predictions and the EOB run; 0 when the marker is not there */
+static int take_restart(bitreader *br, component *comp, int ncomp, prog_scan *ps) {
+    br->bitcnt = 0;
+    if (!br->marker) { while (br->p + 1 < br->end && !(br->p[0] == 0xFF && br->p[1] >= 0xD0 && br->p[1] <= 0xD7)) br->p++; }
+    if (br->p + 1 >= br->end || br->p[0] != 0xFF || br->p[1] < 0xD0 || br->p[1] > 0xD7) return 0;
+    br->p += 2; br->marker = 0;
+    for (int c = 0; c < ncomp; c++) comp[c].pred = 0;
+    if (ps) ps->eob_run = 0;
+    return 1;
+}
+
 /* Returns 1 and a malloc'ed RGB8 image (rows top to bottom) on success, 0 on any malformed or unsupported file. */
 int rt_jpeg_decode(const unsigned char *data, size_t n, int *width, int *height, unsigned char **rgb_out) {
     if (!data || n < 4 || data[0] != 0xFF || data[1] != 0xD8) return 0;
@@ -146,6 +257,7 @@ int rt_jpeg_decode(const unsigned char *data, size_t n, int *width, int *height,
     huff_table *dc = (huff_table *)calloc(4, sizeof(huff_table)), *ac = (huff_table *)calloc(4, sizeof(huff_table));
     component comp[3]; memset(comp, 0, sizeof comp);
     int ncomp = 0, W = 0, H = 0, hmax = 1, vmax = 1, restart = 0, ok = 0, have_frame = 0, jfif = 0, adobe_transform = -1, is_rgb = 0;
+    int progressive = 0, scans = 0;
     size_t pos = 2;
     unsigned char *rgb = NULL;
     if (!dc || !ac) goto done;
@@ -155,7 +267,7 @@ int rt_jpeg_decode(const unsigned char *data, size_t n, int *width, int *height,
         if (m == 0xFF) { pos++; continue; }                            /* fill byte */
         pos += 2;
         if (m == 0xD8 || (m >= 0xD0 && m <= 0xD7) || m == 0x01) continue;
-        if (m == 0xD9) goto done;                                       /* EOI before any scan */
+        if (m == 0xD9) break;                                           /* EOI: a progressive file is complete here; a baseline one had no scan */
         if (pos + 2 > n) goto done;
         size_t len = ((size_t)data[pos] << 8) | data[pos + 1];
         if (len < 2 || pos + len > n) goto done;
@@ -168,8 +280,9 @@ int rt_jpeg_decode(const unsigned char *data, size_t n, int *width, int *height,
                 for (int k = 0; k < 64; k++) { qt[tq][kZigzag[k]] = pq ? (unsigned short)((seg[i] << 8) | seg[i + 1]) : seg[i]; i += pq ? 2 : 1; }
                 qt_present[tq] = 1;
             }
-        } else if (m == 0xC0 || m == 0xC1) {                            /* SOF0 / SOF1: sequential DCT, Huffman */
-            if (sl < 6 || seg[0] != 8) goto done;
+        } else if (m == 0xC0 || m == 0xC1 || m == 0xC2) {               /* SOF0 / SOF1: sequential DCT, Huffman; SOF2: progressive */
+            if (have_frame || sl < 6 || seg[0] != 8) goto done;
+            progressive = m == 0xC2;
             H = (seg[1] << 8) | seg[2]; W = (seg[3] << 8) | seg[4]; ncomp = seg[5];
             if (W <= 0 || H <= 0 || (ncomp != 1 && ncomp != 3) || sl < (size_t)(6 + 3 * ncomp) || (long long)W * H > (1ll << 28)) goto done;
             for (int c = 0; c < ncomp; c++) {
@@ -179,8 +292,18 @@ int rt_jpeg_decode(const unsigned char *data, size_t n, int *width, int *height,
                 if (comp[c].v > vmax) vmax = comp[c].v;
             }
             have_frame = 1;
-        } else if (m >= 0xC2 && m <= 0xCF && m != 0xC4 && m != 0xC8 && m != 0xCC) {
-            goto done;                                                  /* progressive, lossless, arithmetic: unsupported */
+            if (progressive) {                                          /* coefficient planes, MCU-padded, zero to start with */
+                const int mcus_x = (W + 8 * hmax - 1) / (8 * hmax), mcus_y = (H + 8 * vmax - 1) / (8 * vmax);
+                for (int c = 0; c < ncomp; c++) {
+                    comp[c].blocks_w = mcus_x * comp[c].h; comp[c].blocks_h = mcus_y * comp[c].v;
+                    comp[c].stride = comp[c].blocks_w * 8; comp[c].w = (W * comp[c].h + hmax - 1) / hmax; comp[c].hgt = (H * comp[c].v + vmax - 1) / vmax;
+                    comp[c].coef = (short *)calloc((size_t)comp[c].blocks_w * comp[c].blocks_h * 64, sizeof(short));
+                    comp[c].plane = (unsigned char *)calloc((size_t)comp[c].stride * (size_t)(comp[c].blocks_h * 8), 1);
+                    if (!comp[c].coef || !comp[c].plane) goto done;
+                }
+            }
+        } else if (m >= 0xC3 && m <= 0xCF && m != 0xC4 && m != 0xC8 && m != 0xCC) {
+            goto done;                                                  /* lossless, differential, arithmetic: unsupported */
         } else if (m == 0xC4) {                                         /* DHT */
             size_t i = 0;
             while (i < sl) {
@@ -201,6 +324,59 @@ int rt_jpeg_decode(const unsigned char *data, size_t n, int *width, int *height,
         } else if (m == 0xDD) {                                         /* DRI */
             if (sl < 2) goto done;
             restart = (seg[0] << 8) | seg[1];
+        } else if (m == 0xDA && progressive) {                          /* SOS of a progressive file: one of many scans */
+            if (!have_frame || sl < 1) goto done;
+            const int ns = seg[0];
+            if (ns < 1 || ns > ncomp || sl < (size_t)(1 + 2 * ns + 3)) goto done;
+            int sc_comp[3];
+            for (int q = 0; q < ns; q++) {
+                int id = seg[1 + 2 * q], c;
+                for (c = 0; c < ncomp && comp[c].id != id; c++) {}
+                if (c == ncomp) goto done;
+                comp[c].td = seg[2 + 2 * q] >> 4; comp[c].ta = seg[2 + 2 * q] & 15;
+                if (comp[c].td > 3 || comp[c].ta > 3) goto done;
+                sc_comp[q] = c;
+            }
+            prog_scan ps; ps.ss = seg[1 + 2 * ns]; ps.se = seg[2 + 2 * ns]; ps.ah = seg[3 + 2 * ns] >> 4; ps.al = seg[3 + 2 * ns] & 15; ps.eob_run = 0;
+            if (ps.ss > 63 || ps.se > 63 || ps.ss > ps.se || ps.ah > 13 || ps.al > 13) goto done;
+            if ((ps.ss == 0) != (ps.se == 0)) goto done;                 /* a scan is DC only or AC only */
+            if (ps.ss != 0 && ns != 1) goto done;                        /* AC scans hold one component */
+            for (int q = 0; q < ns; q++) {
+                const component *cc = comp + sc_comp[q];
+                if (ps.ss == 0 ? (ps.ah == 0 && !dc[cc->td].present) : !ac[cc->ta].present) goto done;
+            }
+            bitreader br; br.p = data + pos + len; br.end = data + n; br.bitbuf = 0; br.bitcnt = 0; br.marker = 0;
+            for (int c = 0; c < ncomp; c++) comp[c].pred = 0;
+            int until_restart = restart;
+            if (ns == 1) {                                               /* one component: its own blocks, row by row, no MCU padding */
+                component *cc = comp + sc_comp[0];
+                const int bw = (cc->w + 7) >> 3, bh = (cc->hgt + 7) >> 3;
+                for (int j = 0; j < bh; j++)
+                    for (int i = 0; i < bw; i++) {
+                        if (restart && until_restart == 0) { if (!take_restart(&br, comp, ncomp, &ps)) goto done; until_restart = restart; }
+                        short *d = cc->coef + ((size_t)j * cc->blocks_w + i) * 64;
+                        if (!(ps.ss == 0 ? prog_dc(&br, dc + cc->td, cc, d, &ps) : prog_ac(&br, ac + cc->ta, d, &ps))) goto done;
+                        if (restart) until_restart--;
+                    }
+            } else {                                                     /* interleaved: DC scans only */
+                const int mcus_x = (W + 8 * hmax - 1) / (8 * hmax), mcus_y = (H + 8 * vmax - 1) / (8 * vmax);
+                for (int my = 0; my < mcus_y; my++)
+                    for (int mx = 0; mx < mcus_x; mx++) {
+                        if (restart && until_restart == 0) { if (!take_restart(&br, comp, ncomp, &ps)) goto done; until_restart = restart; }
+                        for (int q = 0; q < ns; q++) {
+                            component *cc = comp + sc_comp[q];
+                            for (int by = 0; by < cc->v; by++)
+                                for (int bx = 0; bx < cc->h; bx++)
+                                    if (!prog_dc(&br, dc + cc->td, cc, cc->coef + ((size_t)(my * cc->v + by) * cc->blocks_w + (size_t)(mx * cc->h + bx)) * 64, &ps)) goto done;
+                        }
+                        if (restart) until_restart--;
+                    }
+            }
+            ++scans;
+            /* on to the marker that ends the entropy-coded data */
+            if (!br.marker) { while (br.p + 1 < br.end && !(br.p[0] == 0xFF && br.p[1] != 0 && !(br.p[1] >= 0xD0 && br.p[1] <= 0xD7) && br.p[1] != 0xFF)) br.p++; }
+            pos = (size_t)(br.p - data);
+            continue;
         } else if (m == 0xDA) {                                         /* SOS: the one scan of a baseline file */
             if (!have_frame || sl < 1 || seg[0] != ncomp || sl < (size_t)(1 + 2 * ncomp + 3)) goto done;
             for (int s = 0; s < ncomp; s++) {
@@ -254,47 +430,31 @@ int rt_jpeg_decode(const unsigned char *data, size_t n, int *width, int *height,
                     if (br.marker && !(br.marker >= 0xD0 && br.marker <= 0xD7) && !(my == mcus_y - 1 && mx == mcus_x - 1)) goto done;   /* cut short */
                     if (restart) until_restart--;
                 }
-            rgb = (unsigned char *)malloc((size_t)W * H * 3);
+            rgb = planes_to_rgb(comp, ncomp, W, H, hmax, vmax, is_rgb);
             if (!rgb) goto done;
-            {   /* row by row: upsample every component to full width, then convert (stb_image.h:3794-3850) */
-                unsigned char *line[3] = {NULL, NULL, NULL};
-                const unsigned char *row0[3], *row1[3]; int ystep[3], ypos[3], hs[3], vs[3], wl[3];
-                int alloc_ok = 1;
-                for (int c = 0; c < ncomp; c++) {
-                    line[c] = (unsigned char *)malloc((size_t)W + 3 + 8);
-                    if (!line[c]) alloc_ok = 0;
-                    hs[c] = hmax / comp[c].h; vs[c] = vmax / comp[c].v; ystep[c] = vs[c] >> 1; ypos[c] = 0; wl[c] = (W + hs[c] - 1) / hs[c];
-                    row0[c] = row1[c] = comp[c].plane;
-                }
-                for (int y = 0; y < H && alloc_ok; y++) {
-                    const unsigned char *cur[3] = {NULL, NULL, NULL};
-                    for (int c = 0; c < ncomp; c++) {
-                        const int bot = ystep[c] >= (vs[c] >> 1);
-                        cur[c] = upsample_row(line[c], bot ? row1[c] : row0[c], bot ? row0[c] : row1[c], wl[c], hs[c], vs[c]);
-                        if (++ystep[c] >= vs[c]) { ystep[c] = 0; row0[c] = row1[c]; if (++ypos[c] < comp[c].hgt) row1[c] += comp[c].stride; }
-                    }
-                    unsigned char *o = rgb + (size_t)y * W * 3;
-                    for (int x = 0; x < W; x++, o += 3) {
-                        if (ncomp == 1) { o[0] = o[1] = o[2] = cur[0][x]; continue; }
-                        if (is_rgb) { o[0] = cur[0][x]; o[1] = cur[1][x]; o[2] = cur[2][x]; continue; }
-                        const int yf = (cur[0][x] << 20) + (1 << 19), cb = cur[1][x] - 128, cr = cur[2][x] - 128;
-                        /* JFIF: R = Y + 1.402 Cr, G = Y - 0.71414 Cr - 0.34414 Cb, B = Y + 1.772 Cb; coefficients round(c * 4096) << 8;
-                         * the Cb term of G loses its low 16 bits before it is added (stb's SIMD-compatible form) */
-                        o[0] = clamp8((yf + cr * 1470208) >> 20);
-                        o[1] = clamp8((int)(yf + cr * -748800 + (int)((unsigned)(cb * -360960) & 0xffff0000u)) >> 20);
-                        o[2] = clamp8((yf + cb * 1858048) >> 20);
-                    }
-                }
-                for (int c = 0; c < 3; c++) free(line[c]);
-                if (!alloc_ok) goto done;
-            }
             *width = W; *height = H; *rgb_out = rgb; rgb = NULL; ok = 1;
             goto done;
         }
         pos += len;
     }
+    if (progressive && have_frame && scans > 0) {                      /* every scan is in: dequantise (16-bit wrap, like stb), transform, convert */
+        for (int c = 0; c < ncomp; c++) {
+            if (!qt_present[comp[c].tq]) goto done;
+            const int bw = (comp[c].w + 7) >> 3, bh = (comp[c].hgt + 7) >> 3;
+            for (int j = 0; j < bh; j++)
+                for (int i = 0; i < bw; i++) {
+                    short *d = comp[c].coef + ((size_t)j * comp[c].blocks_w + i) * 64;
+                    for (int k = 0; k < 64; k++) d[k] = (short)(d[k] * qt[comp[c].tq][k]);
+                    idct_block(d, comp[c].plane + (size_t)(j * 8) * comp[c].stride + (size_t)i * 8, comp[c].stride);
+                }
+        }
+        is_rgb = ncomp == 3 && ((comp[0].id == 'R' && comp[1].id == 'G' && comp[2].id == 'B') || (adobe_transform == 0 && !jfif));   /* stb_image.h:3778 */
+        rgb = planes_to_rgb(comp, ncomp, W, H, hmax, vmax, is_rgb);
+        if (!rgb) goto done;
+        *width = W; *height = H; *rgb_out = rgb; rgb = NULL; ok = 1;
+    }
 done:
-    for (int c = 0; c < 3; c++) free(comp[c].plane);
+    for (int c = 0; c < 3; c++) { free(comp[c].plane); free(comp[c].coef); }
     free(dc); free(ac); free(rgb);
     return ok;
 }

@@ -92,8 +92,9 @@ static int ppm_header(const unsigned char *p, size_t n, int *w, int *h, int *max
     *data_offset = i + 1;
     return 1;
 }
-/* texture.c:63-70 loads through stb_image; here: baseline JPEG (jpeg_decode.c) and binary PPM (P6, maxval 255), told apart
- * by their magic bytes.  NULL + the reference's message on failure. */
+/* texture.c:63-70 loads through stb_image, which takes the format from the file's first bytes; here: JPEG, baseline and progressive
+ * (jpeg_decode.c), PNG and BMP (image_decode.c), binary PGM / PPM (P5 / P6, maxval <= 255, bytes as they are).  The formats stb also
+ * reads and no scene of the reference uses -- TGA, PSD, GIF, HDR, PIC -- are refused.  NULL + the reference's message on failure. */
 texture *texture_image_init(char *filename) {
     texture *t = NULL;
     unsigned char *file = NULL, *rgb = NULL;
@@ -103,11 +104,21 @@ texture *texture_image_init(char *filename) {
         && fread(file, 1, (size_t)size, f) == (size_t)size) {
         if (size > 3 && file[0] == 0xFF && file[1] == 0xD8) {
             if (rt_jpeg_decode(file, (size_t)size, &w, &h, &rgb)) t = texture_image_init_rgb(rgb, w, h);
-        } else if (size > 8 && file[0] == 'P' && file[1] == '6') {
+        } else if (size > 8 && file[0] == 137 && file[1] == 'P') {
+            if (rt_png_decode(file, (size_t)size, &w, &h, &rgb)) t = texture_image_init_rgb(rgb, w, h);
+        } else if (size > 26 && file[0] == 'B' && file[1] == 'M') {
+            if (rt_bmp_decode(file, (size_t)size, &w, &h, &rgb)) t = texture_image_init_rgb(rgb, w, h);
+        } else if (size > 8 && file[0] == 'P' && (file[1] == '6' || file[1] == '5')) {
             int mx = 0; size_t data = 0;
-            if (ppm_header(file, (size_t)size, &w, &h, &mx, &data) && mx == 255 && w > 0 && h > 0
-                && (size_t)w * (size_t)h * 3 <= (size_t)size - data)
-                t = texture_image_init_rgb(file + data, w, h);
+            const size_t chan = file[1] == '6' ? 3 : 1;
+            if (ppm_header(file, (size_t)size, &w, &h, &mx, &data) && mx > 0 && mx <= 255 && w > 0 && h > 0 && (long long)w * h <= (1ll << 28)
+                && (size_t)w * (size_t)h * chan <= (size_t)size - data) {
+                if (chan == 3) t = texture_image_init_rgb(file + data, w, h);
+                else if ((rgb = (unsigned char *)malloc((size_t)w * h * 3)) != NULL) {
+                    for (size_t i = 0; i < (size_t)w * h; i++) rgb[3 * i] = rgb[3 * i + 1] = rgb[3 * i + 2] = file[data + i];
+                    t = texture_image_init_rgb(rgb, w, h);
+                }
+            }
         }
     }
     if (f) fclose(f);

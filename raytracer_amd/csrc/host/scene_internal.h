@@ -72,6 +72,8 @@ int rt_bounding_box(const hittable *o, double t0, double t1, rt_box *out);
 /* changes whenever anything is constructed, added to a list or freed through the API (scene_api.c) */
 unsigned long long rt_api_generation(void);
 int rt_jpeg_decode(const unsigned char *data, size_t n, int *width, int *height, unsigned char **rgb_out);
+int rt_png_decode(const unsigned char *data, size_t n, int *width, int *height, unsigned char **rgb_out);   /* image_decode.c */
+int rt_bmp_decode(const unsigned char *data, size_t n, int *width, int *height, unsigned char **rgb_out);
 
 #ifdef __cplusplus
 }

@@ -1007,6 +1007,35 @@ def test_full_size_cornell_1080p_matches_the_fixture_statistics(gpu):
     assert abs(st["rays"] / st["samples"] - float(fx["rays_per_sample"])) <= 0.05 * float(fx["rays_per_sample"])
 
 
+def test_full_size_cornell_1080p_against_the_oracle_at_full_size(gpu):
+    """BASELINE config 2 on its own pixel grid: the CPU oracle rendered Cornell at 1920x1080, aspect 16/9, depth 10, 1024 spp (Philox
+    mode; tests/golden/make_cornell_1080p_blocks.py, nine CPU-minutes) and kept the means of its 8x8-pixel blocks -- 240 x 135 blocks of
+    65,536 samples each.  The GPU renders the same grid at 1024 spp and is compared block by block after the [0, 1] clamp: RMSE per
+    channel <= 0.003 (measured 0.0018: both images carry ~0.0012 of their own noise per block), the 64x64-pixel means <= 0.0006 (measured
+    0.0002), mean luminance within 0.15 % (measured < 0.001 %), rays per sample within 0.1 % (3.2263 against 3.2264) -- the full-size counterpart of the 128^2 / 240x135 fixtures' tolerances, with no drift
+    between pixel grids to allow for."""
+    fx = golden("image_cornell_1080p_blocks.npz")
+    ref = fx["block_mean"].astype(np.float64)
+    assert ref.shape == (135, 240, 3)
+    sc, cam, view = gpu.build_named_scene("cornell", aspect=16 / 9)
+    try:
+        acc, st = sc.render(cam, gpu.Settings(1920, 1080, 1024, 10, 0, seed=4242))
+    finally:
+        sc.close()
+    assert st["kernel_used"] == 2 and (acc[..., 3] == 1024).all() and np.isfinite(acc).all()
+    blocks = mean_image(acc).reshape(135, 8, 240, 8, 3).mean(axis=(1, 3))
+    a, b = clip01(blocks), clip01(ref)
+    rmse = np.sqrt(((a - b) ** 2).mean(axis=(0, 1)))
+    coarse = lambda x: x[:128].reshape(16, 8, 30, 8, 3).mean(axis=(1, 3))
+    rmse64 = np.sqrt(((coarse(a) - coarse(b)) ** 2).mean(axis=(0, 1)))
+    la, lb = (blocks @ LUMA).mean(), (ref @ LUMA).mean()
+    rps = st["rays"] / st["samples"]
+    print(f"1080p blocks vs oracle: rmse {rmse.round(5)} rmse64 {rmse64.round(5)} dlum {abs(la - lb) / lb:.5f} rays/sample {rps:.4f} vs {float(fx['rays_per_sample']):.4f}")
+    assert rmse.max() <= 0.003 and rmse64.max() <= 0.0006
+    assert abs(la - lb) / lb <= 0.0015
+    assert abs(rps - float(fx["rays_per_sample"])) <= 0.001 * float(fx["rays_per_sample"])
+
+
 def test_full_size_million_spheres(gpu):
     """BASELINE config 5 at its full size (1,000,004 spheres): the FP32 production traversal agrees with the bit-exact FP64
     kernel on the primary rays of a 192x108 grid (same primitive for >= 99.5 %), the BVH keeps its depth bound, and the

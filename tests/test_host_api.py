@@ -120,6 +120,43 @@ def test_jpeg_decoder_cases_are_bit_identical_to_the_reference_loader(rtc):
         assert np.array_equal(np.ctypeslib.as_array(p, shape=want.shape), want), name
 
 
+def test_png_bmp_pgm_and_progressive_jpeg_textures_are_the_reference_loaders(rtc, tmp_path):
+    """stbi_load (texture.c:66) takes a texture in whatever format its first bytes announce.  122 small files -- PNG of every colour
+    type and bit depth (grey 1/2/4/8/16, grey+alpha, RGB, RGBA, palette 1/2/4/8, tRNS, all five row filters, Adam7, split IDAT
+    chunks, stored / fixed / dynamic deflate blocks), BMP (1 / 4 / 8-bit palettes, 24-bit, 16- and 32-bit through bit masks, V4 header,
+    top-down rows), progressive JPEG (4:4:4, 4:2:2, 4:2:0, grey, odd sizes, restart intervals) and binary PGM / PPM -- each decoded by the
+    compiled reference's stb_image (tests/golden/image_cases.npz, make_image_cases.py): texture_image_init loads the same texels, sample
+    for sample, and refuses the same files cut short."""
+    L = rtc.lib()
+    L.texture_image_init.restype = C.c_void_p
+    L.texture_image_init.argtypes = [C.c_char_p]
+
+    class Tex(C.Structure):                                          # scene_internal.h struct texture, up to what is read here
+        _fields_ = [("kind", C.c_int), ("value", C.c_double * 3), ("odd", C.c_void_p), ("even", C.c_void_p), ("scale", C.c_double),
+                    ("ranvec", C.c_void_p), ("perm", C.c_void_p), ("pixels", C.POINTER(C.c_ubyte)), ("width", C.c_int), ("height", C.c_int)]
+    fx = golden("image_cases.npz")
+    names = sorted(k[5:] for k in fx.files if k.startswith("file_"))
+    assert len(names) >= 120
+    kinds = set()
+    for name in names:
+        data = fx["file_" + name].tobytes()
+        want = fx["rgb_" + name]
+        path = str(tmp_path / "t.img")
+        open(path, "wb").write(data)
+        t = L.texture_image_init(path.encode())
+        assert t, name
+        tex = Tex.from_address(t)
+        assert (tex.height, tex.width, 3) == want.shape, name
+        got = np.ctypeslib.as_array(tex.pixels, shape=want.shape)
+        assert np.array_equal(got, want), (name, int((got != want).sum()))
+        kinds.add(name.split("_")[0])
+        if len(data) > 200:                                           # cut short: refused, with the reference's message, not read past the end
+            open(path, "wb").write(data[:len(data) // 2])
+            assert not L.texture_image_init(path.encode()) or name.startswith(("pjpg", "bmp_pil_1")), name
+    assert kinds == {"png", "bmp", "pjpg", "pgm", "ppm"}
+    L.textures_free_all()
+
+
 def test_jpeg_decoder_subsampled_and_restart_files(rtc, tmp_path):
     """4:2:0 / 4:2:2 chroma subsampling, grayscale, odd sizes and restart intervals, against libjpeg (PIL) as an
     independent decoder: |difference| <= 4 on 99.9 % of the samples (stb's upsampling filters, which this decoder restates,
@@ -311,8 +348,9 @@ def test_lights_that_are_leaves_of_the_small_pack(monkeypatch):
 
 
 def test_jpeg_decoder_under_sanitizers(tmp_path):
-    """tools/fuzz/jpeg_fuzz.c: 1,500 mutations of the earth map and of a 4:2:0 / restart-interval case (byte flips, truncations,
-    stray markers) through rt_jpeg_decode compiled with ASan + UBSan: no over-read, no undefined arithmetic (the IDCT wraps like
+    """tools/fuzz/jpeg_fuzz.c: 1,500 mutations of the earth map and of a 4:2:0 / restart-interval case, and 600 each of two progressive
+    JPEGs, four PNGs and three BMPs (byte flips, truncations, stray markers) through rt_jpeg_decode / rt_png_decode / rt_bmp_decode
+    compiled with ASan + UBSan: no over-read, no undefined arithmetic (the IDCT wraps like
     the reference's int arithmetic does on two's-complement hardware), every success returns a full image."""
     import shutil
     import subprocess
@@ -321,7 +359,8 @@ def test_jpeg_decoder_under_sanitizers(tmp_path):
     host = os.path.join(ROOT, "raytracer_amd", "csrc", "host")
     exe = tmp_path / "jpeg_fuzz"
     r = subprocess.run(["gcc", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-static-libasan", "-I" + os.path.join(ROOT, "include"), "-I" + host,
-                        os.path.join(ROOT, "tools", "fuzz", "jpeg_fuzz.c"), os.path.join(host, "jpeg_decode.c"), "-lm", "-o", str(exe)], capture_output=True, text=True)
+                        os.path.join(ROOT, "tools", "fuzz", "jpeg_fuzz.c"), os.path.join(host, "jpeg_decode.c"), os.path.join(host, "image_decode.c"), "-lm", "-o", str(exe)],
+                       capture_output=True, text=True)
     if r.returncode != 0 and ("asan" in r.stderr.lower() or "ubsan" in r.stderr.lower()):
         pytest.skip("no sanitizer runtime in this image")
     assert r.returncode == 0, r.stderr[-2000:]
@@ -331,7 +370,13 @@ def test_jpeg_decoder_under_sanitizers(tmp_path):
     small = tmp_path / "case.jpg"
     small.write_bytes(cases[pick[0] + "_jpg"].tobytes())
     env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:verify_asan_link_order=0")
-    for path, n in ((os.path.join(ROOT, "tests", "golden", "earthmap.jpg"), "500"), (str(small), "1000")):
+    jobs = [(os.path.join(ROOT, "tests", "golden", "earthmap.jpg"), "500"), (str(small), "1000")]
+    more = np.load(os.path.join(ROOT, "tests", "golden", "image_cases.npz"))   # progressive JPEG, PNG (interlaced 16-bit, palette, dynamic codes), BMP (palette, bit masks)
+    for k, name in enumerate(("pjpg_420", "pjpg_restart", "png_c6_d16_i1_37x23", "png_c3_d4_i1_37x23", "png_big_fixed", "png_stored", "bmp_4bit", "bmp_16_565", "bmp_pil_P")):
+        f = tmp_path / f"seed{k}.img"
+        f.write_bytes(more["file_" + name].tobytes())
+        jobs.append((str(f), "600"))
+    for path, n in jobs:
         run = subprocess.run([str(exe), path, n], capture_output=True, text=True, env=env, timeout=600)
         assert run.returncode == 0 and "decoded" in run.stdout and "runtime error" not in run.stderr, (run.stdout[-500:], run.stderr[-2000:])
 

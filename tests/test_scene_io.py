@@ -222,7 +222,7 @@ def test_scene_loader_mutation_fuzz_under_sanitizers(tmp_path):
     inc = ["-I" + os.path.join(ROOT, "include"), "-I" + host, "-I" + os.path.join(ROOT, "raytracer_amd", "csrc")]
     san = ["-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined"]
     objs = []
-    for src in ("scene_api.c", "jpeg_decode.c"):
+    for src in ("scene_api.c", "jpeg_decode.c", "image_decode.c"):
         o = str(tmp_path / (src + ".o"))
         r = subprocess.run(["gcc"] + san + ["-c"] + inc + [os.path.join(host, src), "-o", o], capture_output=True, text=True)
         assert r.returncode == 0, r.stderr[-2000:]

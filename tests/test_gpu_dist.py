@@ -100,7 +100,7 @@ def test_c_abi_multi_device_render_has_no_serial_tail(gpu):
         st = gpu.Settings(W, H, spp, view.max_depth, view.integrator, seed=9)
         handles = (C.c_void_p * 2)(sc.handle, clone)
         one, two = [], []
-        for rep in range(4):                                             # the first round allocates
+        for rep in range(6):                                             # the first round allocates; minimum of the other five (a shared box is noisy)
             acc = np.zeros((H, W, 4), dtype=np.float32)
             t0 = time.perf_counter(); sc.render(cam, st, accum=acc); one.append(time.perf_counter() - t0)
             acc2 = np.zeros((H, W, 4), dtype=np.float32)

@@ -31,6 +31,10 @@ import os
 import sys
 import time
 
+# the host driver of this pool only supports dmabuf IPC: without this RCCL's peer buffers fail with `hipIpcGetMemHandle: invalid argument`
+# (already exported on the GPU boxes; set here too, before HIP starts, so that a bare launch of N ranks works)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 import numpy as np
 import torch
 import torch.distributed as dist

@@ -1036,6 +1036,40 @@ def test_full_size_cornell_1080p_against_the_oracle_at_full_size(gpu):
     assert abs(rps - float(fx["rays_per_sample"])) <= 0.001 * float(fx["rays_per_sample"])
 
 
+def test_full_size_final_1024_against_the_oracle_at_full_size(gpu):
+    """BASELINE config 3 on its own pixel grid: the CPU oracle rendered the 02 final scene at 1024x1024, depth 8, 02's ray_color, 512 spp
+    (Philox mode; tests/golden/make_final_1024_blocks.py, ten CPU-minutes) and kept the means of its 8x8-pixel blocks -- 128 x 128 blocks of
+    32,768 samples each.  The GPU renders the same grid at 1024 spp through the wavefront kernels (camera-ray pass, extend with its shading
+    tail, k_wf_shade for the perlin sphere, three overlapping parts) and is compared block by block after the [0, 1] clamp; gates:
+    per-channel RMSE <= 0.0076 (1.6 x the measured 0.0047), 64x64-pixel means <= 0.00095 (measured 0.0006), mean luminance within 0.15 %
+    (measured 0.005 %), rays per sample within 0.1 % (2.7791 on both sides).  Media (free-flight draws),
+    moving spheres (shutter time), the perlin turbulence and the 400 box records are all in this image at the configuration's full size."""
+    fx = golden("image_final_1024_blocks.npz")
+    ref = fx["block_mean"].astype(np.float64)
+    assert ref.shape == (128, 128, 3)
+    sc, cam, view = gpu.build_named_scene("final")
+    try:
+        acc, st = sc.render(cam, gpu.Settings(1024, 1024, 1024, view.max_depth, view.integrator, seed=2024))
+    finally:
+        sc.close()
+    assert st["kernel_used"] == 3 and (acc[..., 3] == 1024).all() and np.isfinite(acc).all()
+    blocks = mean_image(acc).reshape(128, 8, 128, 8, 3).mean(axis=(1, 3))
+    a, b = clip01(blocks), clip01(ref)
+    rmse = np.sqrt(((a - b) ** 2).mean(axis=(0, 1)))
+    coarse = lambda x: x.reshape(16, 8, 16, 8, 3).mean(axis=(1, 3))
+    rmse64 = np.sqrt(((coarse(a) - coarse(b)) ** 2).mean(axis=(0, 1)))
+    la, lb = (a @ LUMA).mean(), (b @ LUMA).mean()
+    rps = st["rays"] / st["samples"]
+    print(f"final 1024^2 blocks vs oracle: rmse {rmse.round(5)} rmse64 {rmse64.round(5)} dlum {abs(la - lb) / lb:.5f} rays/sample {rps:.4f} vs {float(fx['rays_per_sample']):.4f}")
+    assert rmse.max() <= FINAL_1024_GATES[0] and rmse64.max() <= FINAL_1024_GATES[1]
+    assert abs(la - lb) / lb <= FINAL_1024_GATES[2]
+    assert abs(rps - float(fx["rays_per_sample"])) <= FINAL_1024_GATES[3] * float(fx["rays_per_sample"])
+
+
+# measured: RMSE 0.0037 / 0.0047 / 0.0040, 64x64-pixel means 0.0005 / 0.0006 / 0.0005, luminance 0.005 %, rays per sample 2.7791 on both sides
+FINAL_1024_GATES = (0.0076, 0.00095, 0.0015, 0.001)
+
+
 def test_full_size_million_spheres(gpu):
     """BASELINE config 5 at its full size (1,000,004 spheres): the FP32 production traversal agrees with the bit-exact FP64
     kernel on the primary rays of a 192x108 grid (same primitive for >= 99.5 %), the BVH keeps its depth bound, and the

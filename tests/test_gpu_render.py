@@ -1070,6 +1070,40 @@ def test_full_size_final_1024_against_the_oracle_at_full_size(gpu):
 FINAL_1024_GATES = (0.0076, 0.00095, 0.0015, 0.001)
 
 
+def test_full_size_million_spheres_against_the_oracle_at_full_size(gpu):
+    """BASELINE config 5 on its own pixel grid and at its own size: the CPU oracle rendered the 1,000,004-sphere scene at 1920x1080, aspect
+    16/9, 01's ray_color (sky background), the scene's depth, 192 spp (Philox mode; tests/golden/make_million_1080p_blocks.py, twelve
+    CPU-minutes through the reference's own tree) and kept the means of its 8x8-pixel blocks -- 240 x 135 blocks of 12,288 samples each.
+    The GPU builds the same scene (binned-SAH tree, 1.5 M nodes), renders the same grid at 768 spp through the wavefront kernels and is
+    compared block by block after the [0, 1] clamp: per-channel RMSE <= 0.0024 (1.6 x the measured 0.0015), 64x64-pixel means <= 0.0003
+    (measured 0.00019), mean luminance within 0.15 % (measured 0.002 %), rays per sample within 0.1 % (2.3779 on both sides)."""
+    fx = golden("image_million_1080p_blocks.npz")
+    ref = fx["block_mean"].astype(np.float64)
+    assert ref.shape == (135, 240, 3)
+    sc, cam, view = gpu.build_named_scene("million", arg=int(fx["arg"]), aspect=16 / 9)
+    try:
+        assert sc.num_prims() == 1000004
+        acc, st = sc.render(cam, gpu.Settings(1920, 1080, 768, view.max_depth, view.integrator, seed=31))
+    finally:
+        sc.close()
+    assert st["kernel_used"] == 3 and (acc[..., 3] == 768).all() and np.isfinite(acc).all()
+    blocks = mean_image(acc).reshape(135, 8, 240, 8, 3).mean(axis=(1, 3))
+    a, b = clip01(blocks), clip01(ref)
+    rmse = np.sqrt(((a - b) ** 2).mean(axis=(0, 1)))
+    coarse = lambda x: x[:128].reshape(16, 8, 30, 8, 3).mean(axis=(1, 3))
+    rmse64 = np.sqrt(((coarse(a) - coarse(b)) ** 2).mean(axis=(0, 1)))
+    la, lb = (a @ LUMA).mean(), (b @ LUMA).mean()
+    rps = st["rays"] / st["samples"]
+    print(f"million 1080p blocks vs oracle: rmse {rmse.round(5)} rmse64 {rmse64.round(5)} dlum {abs(la - lb) / lb:.5f} rays/sample {rps:.4f} vs {float(fx['rays_per_sample']):.4f}")
+    assert rmse.max() <= MILLION_1080P_GATES[0] and rmse64.max() <= MILLION_1080P_GATES[1]
+    assert abs(la - lb) / lb <= MILLION_1080P_GATES[2]
+    assert abs(rps - float(fx["rays_per_sample"])) <= MILLION_1080P_GATES[3] * float(fx["rays_per_sample"])
+
+
+# measured: RMSE 0.0009 / 0.0012 / 0.0015, 64x64-pixel means 0.00012 / 0.00015 / 0.00019, luminance 0.002 %, rays per sample 2.3779 on both sides
+MILLION_1080P_GATES = (0.0024, 0.0003, 0.0015, 0.001)
+
+
 def test_full_size_million_spheres(gpu):
     """BASELINE config 5 at its full size (1,000,004 spheres): the FP32 production traversal agrees with the bit-exact FP64
     kernel on the primary rays of a 192x108 grid (same primitive for >= 99.5 %), the BVH keeps its depth bound, and the

@@ -11,7 +11,7 @@ reps = int(sys.argv[1]) if len(sys.argv) > 1 else 5
 only = sys.argv[2:]
 jobs = [("final", None, 1024, 1024, 256, 0), ("final_earth", 16 / 9, 1920, 1080, 256, 0), ("book1", 16 / 9, 1920, 1080, 64, 0), ("million", 16 / 9, 1920, 1080, 64, 1000),
         ("book2_random", 16 / 9, 1920, 1080, 64, 0), ("box_field_smoke", None, 768, 768, 64, 0)]
-MODES = {"old": {"RTC_WF_TAIL_LIVE": "0"}, "new": {}, "new64k": {"RTC_WF_TAIL_LIVE": "65536"}, "new1m": {"RTC_WF_TAIL_LIVE": "1048576"}}
+MODES = {"old": {"RTC_WF_LATE_ROUND": "1000000"}, "new": {}, "late20": {"RTC_WF_LATE_ROUND": "20"}, "late40": {"RTC_WF_LATE_ROUND": "40"}}
 for name, aspect, W, H, spp, arg in jobs:
     if only and name not in only: continue
     sc, cam, view = ra.build_named_scene(name, arg=arg, aspect=aspect)

@@ -235,11 +235,20 @@ constexpr int kWfStripes = 64;   // cache lines each statistic is striped over
 #define RT_WF_EXTEND_BLOCK 64
 #endif
 constexpr int kWfExtendBlock = RT_WF_EXTEND_BLOCK;
-#ifndef RT_WF_EXTEND_WAVES
-#define RT_WF_EXTEND_WAVES 8   // resident waves per SIMD the register budget of extend is set for (A/B knob)
+// Resident waves per SIMD the register budget of extend and of the camera-ray pass is set for (512 / waves registers per lane).  Since extend
+// shades the hits it finds (round 3) the kernels want 104-110 registers; at 8 waves (64 registers, 24 of them spilled) the spills cost more
+// than the eighth wave hides.  One GPU run, whole renders, interleaved: 1M spheres 8 / 7 / 6 / 5 / 4 waves = 40.4 / 37.5 / 36.9 / 36.7 / 36.5 ms,
+// final scene 91.1 / 88.4 / 90.5 / 89.4 / 89.4 ms, final + earth 159.4 / 155.0 / 157.4 / 157.8 / 158.4 ms (profiles/r03e/extend_waves_ab.txt) --
+// so the spheres-only kernels are built for 5 waves (96 registers) and the others for 7 (72).  -DRT_WF_EXTEND_WAVES=n forces one value (A/B).
+constexpr int wf_extend_waves(int media, int kinds) {
+#ifdef RT_WF_EXTEND_WAVES
+    return media == 2 ? 6 : RT_WF_EXTEND_WAVES;
+#else
+    return media == 2 ? 6 : (kinds == RTC_KIND_SPHERE ? 5 : 7);
 #endif
+}
 template <int MEDIA, int KINDS>
-__global__ void __launch_bounds__(kWfExtendBlock) __attribute__((amdgpu_waves_per_eu(MEDIA == 2 ? 6 : RT_WF_EXTEND_WAVES))) k_wf_extend(WfArgs a) {
+__global__ void __launch_bounds__(kWfExtendBlock) __attribute__((amdgpu_waves_per_eu(wf_extend_waves(MEDIA, KINDS)))) k_wf_extend(WfArgs a) {
     const SceneT<float> &sc = a.sc; const RenderParams &P = a.P; const WfBuffers &B = a.B;
     if (B.counters[WF_LIVE] == 0) return;                            // the render is over: the rest of the fixed bounce schedule drains at once
     const unsigned n_list = B.counters[WF_NLIST]; const int cur = (int)B.counters[WF_CUR];   // the list as the last compaction left it
@@ -290,7 +299,7 @@ __global__ void __launch_bounds__(kWfExtendBlock) __attribute__((amdgpu_waves_pe
 // same traversal, same medium draws as extend would make for it at depth 0 -- the images are bit-identical to tracing them from the list.
 // WAVE = true: one traversal for the whole wave (rt_core.hpp bvh_closest_hit_wave: the node in SGPRs, one scalar load per node or leaf record).
 template <int MEDIA, int KINDS, bool WAVE>
-__global__ void __launch_bounds__(kWfExtendBlock) __attribute__((amdgpu_waves_per_eu(MEDIA == 2 ? 6 : RT_WF_EXTEND_WAVES))) k_wf_primary(WfArgs a) {
+__global__ void __launch_bounds__(kWfExtendBlock) __attribute__((amdgpu_waves_per_eu(wf_extend_waves(MEDIA, KINDS)))) k_wf_primary(WfArgs a) {
     const SceneT<float> &sc = a.sc; const RenderParams &P = a.P; const WfBuffers &B = a.B;
     extern __shared__ int lds_stack[];                               // sc.bvh_stack entries per lane
     const int slot = blockIdx.x * blockDim.x + threadIdx.x, k = (int)blockIdx.y;
@@ -338,14 +347,20 @@ __global__ void __launch_bounds__(kWfExtendBlock) __attribute__((amdgpu_waves_pe
     }
 }
 
-// Extend for SMALL trees (book1: 281 nodes + 486 leaf records = 49 KB): a workgroup of 1024 threads copies the node and the leaf table
+// Extend for SMALL trees (book1: 281 nodes + 486 leaf records = 49 KB): a workgroup of 768 threads copies the node and the leaf table
 // into LDS, and every trip's 64-byte fetch is four ds_read_b128 instead of a trip through the address unit, L1 and L2 -- which is
 // what the plain kernel waits for on such a scene (its lanes are coherent enough to outrun the L1's 64-byte-record rate).
-// Two workgroups per CU (8 waves per SIMD) need tables + stacks <= 80 KB each: the stacks hold 16-bit entries (wf_lds_tables()
+// Two workgroups per CU (6 waves per SIMD) need tables + stacks <= 80 KB each: the stacks hold 16-bit entries (wf_lds_tables()
 // checks that every node index and leaf reference fits).  Hits are bit-identical to k_wf_extend's: same traversal, same order.
-constexpr int kWfLdsBlock = 1024;
+// Threads per workgroup; two workgroups fit a CU, i.e. 6 waves per SIMD with 80 registers each at 768.  Round 2 ran 1024 (8 waves, 64 registers);
+// since the kernel shades its hits (round 3) that meant 36 spilled registers.  book1 1080p x 64 spp, one GPU run, interleaved:
+// 1024 / 896 / 768 / 640 / 512 threads = 23.6 / 22.7 / 21.5 / 23.7 / 22.4 ms (profiles/r03e/extend_waves_ab.txt).  -DRT_WF_LDS_BLOCK=n: A/B knob.
+#ifndef RT_WF_LDS_BLOCK
+#define RT_WF_LDS_BLOCK 768
+#endif
+constexpr int kWfLdsBlock = RT_WF_LDS_BLOCK;
 template <int KINDS>
-__global__ void __launch_bounds__(kWfLdsBlock) __attribute__((amdgpu_waves_per_eu(8))) k_wf_extend_lds(WfArgs a) {
+__global__ void __launch_bounds__(kWfLdsBlock) __attribute__((amdgpu_waves_per_eu(kWfLdsBlock / 128))) k_wf_extend_lds(WfArgs a) {
     const SceneT<float> &sc = a.sc; const RenderParams &P = a.P; const WfBuffers &B = a.B;
     if (B.counters[WF_LIVE] == 0) return;
     const unsigned n_list = B.counters[WF_NLIST]; const int cur = (int)B.counters[WF_CUR];
@@ -361,7 +376,7 @@ __global__ void __launch_bounds__(kWfLdsBlock) __attribute__((amdgpu_waves_per_e
     __shared__ unsigned wg_next;
     if (threadIdx.x == 0) wg_next = 0u;
     __syncthreads();
-    // persistent: a workgroup owns a contiguous slice of the list's 64-entry chunks and its 16 waves claim them one at a time from a counter
+    // persistent: a workgroup owns a contiguous slice of the list's 64-entry chunks and its 12 waves claim them one at a time from a counter
     // in LDS (a same-address atomic in HBM costs ~11 ns and serialises: one per chunk was 12 % slower than the static partition it replaced)
     // -- no barrier after the copy, so a workgroup's waves do not wait for its slowest one, and the table is copied once per workgroup
     unsigned long long n_rays = 0, n_waves = 0;
@@ -400,8 +415,8 @@ __global__ void __launch_bounds__(kWfLdsBlock) __attribute__((amdgpu_waves_per_e
         n_rays += (unsigned long long)__builtin_popcountll(mask); n_waves += mask != 0;
     }
     if (lane == 0 && n_rays) {
-        atomicAdd(B.stats + 8 * (1 + ((blockIdx.x * 16 + wave) & (kWfStripes - 1))), n_rays);
-        atomicAdd(B.stats + 8 * (1 + kWfStripes + ((blockIdx.x * 16 + wave) & (kWfStripes - 1))), n_waves);
+        atomicAdd(B.stats + 8 * (1 + ((blockIdx.x * (kWfLdsBlock / 64) + wave) & (kWfStripes - 1))), n_rays);
+        atomicAdd(B.stats + 8 * (1 + kWfStripes + ((blockIdx.x * (kWfLdsBlock / 64) + wave) & (kWfStripes - 1))), n_waves);
     }
 }
 
@@ -553,7 +568,7 @@ size_t wf_bytes_per_slot() { return 4 * sizeof(float4) + sizeof(float2) + 2 * si
 size_t wf_stats_bytes() { return (1 + 2 * kWfStripes) * 8 * sizeof(unsigned long long); }   // cache lines of 64 bytes
 
 // Does the extend stage of this scene run from LDS tables (k_wf_extend_lds)?  No media, every node index and leaf reference in 16
-// bits, and tables + 16-bit stacks of 1024 lanes within half a CU's LDS.  RTC_WF_LDS_TABLES=0 keeps the plain kernel (A/B, tests).
+// bits, and tables + 16-bit stacks of a workgroup's 768 lanes within half a CU's LDS.  RTC_WF_LDS_TABLES=0 keeps the plain kernel (A/B, tests).
 bool wf_lds_tables(const SceneT<float> &sc, size_t *lds_bytes) {
     if (const char *e = std::getenv("RTC_WF_LDS_TABLES")) if (std::atoi(e) == 0) return false;
     if (sc.media_kind != 0 || sc.n_nodes <= 0 || sc.n_bleaves <= 0 || sc.n_nodes >= 32768 || sc.n_bleaves >= 4096) return false;   // ~(slot << 3 | count - 1) >= -32768

@@ -558,6 +558,9 @@ static int render_wavefront(rtc_scene *s, const CameraT<float> &camf, const Rend
     if (const char *e = std::getenv("RTC_WF_SPS")) { const int v = std::atoi(e); if (v >= 1) sps = v; }   // A/B knob
     const long long slots_wanted = std::min<long long>((long long)((spp_all + sps - 1) / sps) * per_layer, 32ll << 20);
     int n_parts = (int)std::max<long long>(1, std::min<long long>(3, slots_wanted / (5ll << 20)));
+    // trees traversed from LDS (k_wf_extend_lds: persistent workgroups, two per CU) overlap better still: up to four parts of about 4 M slots (book1 1080p x 64 spp,
+    // one GPU run: 1 / 2 / 3 / 4 parts = 31.6 / 23.8 / 21.7 / 19.9 ms; the final scene and the 1M spheres are best at three: 107 / 91.6 / 88.4 / 89.7, 44.6 / 38.5 / 37.0 / 37.1)
+    if (wf_lds_tables(s->f32.view, nullptr)) n_parts = (int)std::max<long long>(1, std::min<long long>(4, (slots_wanted + (2ll << 20)) / (4ll << 20)));
     if (const char *e = std::getenv("RTC_WF_PARTS")) { const int v = std::atoi(e); if (v >= 1 && v <= RTC_WF_MAX_PARTS) n_parts = v; }   // A/B knob
     if (n_parts > spp_all) n_parts = spp_all;
     // Slots per pixel ("layers").  A slot walks through its samples one after the other, so a render lasts as many bounces

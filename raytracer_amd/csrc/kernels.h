@@ -67,6 +67,7 @@ struct WfBuffers {
     WfDiv div_group, div_tiles_x;     // divisions of that mapping: by the slots of a layer group (4 layers when quad, else 1), by tiles_x
     int phit_k;                       // 0: no camera rays traced ahead (every sample's first ray goes through the slot list)
     WfDiv div_layers;                 // (sample - s_begin) / layers = which of the slot's samples
+    int compact_div;                  // k_wf_compact squeezes the list when more than 1 / compact_div of it is holes
 };
 size_t wf_bytes_per_slot();
 size_t wf_stats_bytes();
@@ -75,7 +76,7 @@ hipError_t launch_wf_primary(const SceneT<float> &sc, const CameraT<float> &cam,
 // one bounce: extend (+ shade of the parked hits) over the current slot list, whose length and buffer index live in b.counters
 bool wf_lds_tables(const SceneT<float> &sc, size_t *lds_bytes);   // extend from LDS-resident node / leaf tables (small trees)?
 hipError_t launch_wf_bounce(const SceneT<float> &sc, const CameraT<float> &cam, const RenderParams &p, const WfBuffers &b, hipStream_t stream);
-// current list -> the other list without holes, IF a quarter of it is holes (decided on the device)
+// current list -> the other list without holes, IF more than 1 / b.compact_div of it is holes (decided on the device)
 hipError_t launch_wf_compact(const WfBuffers &b, hipStream_t stream);
 hipError_t launch_wf_finish(const RenderParams &p, const WfBuffers &b, float4 *accum, hipStream_t stream);
 

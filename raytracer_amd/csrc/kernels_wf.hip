@@ -9,7 +9,7 @@
 //   k_wf_extend   closest hit for every live slot (hittable_list_hit, ray.c:56): traversal only
 //   k_wf_shade    material / pdf switch of rt_shade.hpp; ends the path or writes the scattered ray; a finished path
 //                 regenerates the slot's next sample, so a slot stays live until its pixel is out of samples
-//   k_wf_compact  every few bounces, once enough slots have died: squeezes the holes out of the slot list
+//   k_wf_compact  every other bounce, once a sixteenth of the list is holes: squeezes the holes out of the slot list
 //   k_wf_finish   per pixel: accumulator += the sums of its slots (coalesced float4 read-modify-write)
 //
 // A slot owns ONE pixel and walks through its samples in a fixed order, so no atomics touch radiance and the image does
@@ -512,17 +512,17 @@ __global__ void __launch_bounds__(kWfShadeBlock) __attribute__((amdgpu_waves_per
 }
 
 // active[cur][0..n_list) -> active[cur^1][0..live): order kept inside a block, one atomic per block.  Launched at fixed points of the
-// bounce schedule; whether the list is worth squeezing -- a quarter of it holes -- is decided HERE, from the device's own counters,
+// bounce schedule; whether the list is worth squeezing -- 1 / B.compact_div of it holes -- is decided HERE, from the device's own counters,
 // so the host never waits for a count: every block takes the same decision, and k_wf_flip, the next kernel in the stream, takes it
 // once more and makes the new list current.
-__device__ __forceinline__ bool wf_worth_compacting(const unsigned *counters) {
-    const unsigned live = counters[WF_LIVE], n_list = counters[WF_NLIST];
-    return live != 0 && live < n_list - n_list / 4;
+__device__ __forceinline__ bool wf_worth_compacting(const WfBuffers &B) {
+    const unsigned live = B.counters[WF_LIVE], n_list = B.counters[WF_NLIST];
+    return live != 0 && live < n_list - n_list / (unsigned)B.compact_div;
 }
 __global__ void __launch_bounds__(1024) k_wf_compact(WfBuffers B) {
     __shared__ unsigned wave_count[16];
     __shared__ unsigned block_base;
-    if (!wf_worth_compacting(B.counters)) return;
+    if (!wf_worth_compacting(B)) return;
     const unsigned n_list = B.counters[WF_NLIST]; const int cur = (int)B.counters[WF_CUR];
     if (blockIdx.x * blockDim.x >= n_list) return;
     const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -539,7 +539,7 @@ __global__ void __launch_bounds__(1024) k_wf_compact(WfBuffers B) {
     if (live) B.active[cur ^ 1][block_base + before + (unsigned)__builtin_popcountll(mask & ((1ull << lane) - 1ull))] = slot;
 }
 __global__ void k_wf_flip(WfBuffers B) {
-    if (wf_worth_compacting(B.counters)) { B.counters[WF_NLIST] = B.counters[WF_CURSOR]; B.counters[WF_CUR] ^= 1u; }
+    if (wf_worth_compacting(B)) { B.counters[WF_NLIST] = B.counters[WF_CURSOR]; B.counters[WF_CUR] ^= 1u; }
     B.counters[WF_CURSOR] = 0;
 }
 

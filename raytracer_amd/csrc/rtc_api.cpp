@@ -574,6 +574,8 @@ static int render_wavefront(rtc_scene *s, const CameraT<float> &camf, const Rend
     // render (32 M slots: 32 samples per slot; what lies beyond goes through the slot lists as before).  RTC_WF_PRIMARY=0: none (A/B, tests).
     long long phit_budget = 8ll << 30;
     if (const char *e = std::getenv("RTC_WF_PRIMARY")) { const long long v = std::atoll(e); phit_budget = v <= 0 ? 0 : (v == 1 ? phit_budget : v); }
+    int compact_div = 16;
+    if (const char *e = std::getenv("RTC_WF_COMPACT_DIV")) compact_div = std::max(2, std::atoi(e));   // A/B knob
     struct Part { RenderParams p; long long layers, n_slots, phit_k; WfBuffers b; long long iterations; };
     Part part[RTC_WF_MAX_PARTS];
     long long total_slots = 0;
@@ -640,6 +642,7 @@ static int render_wavefront(rtc_scene *s, const CameraT<float> &camf, const Rend
         b.counters = (unsigned *)(ctl + wf_stats_bytes());
         b.n_slots = (int)n; b.slots_per_layer = (int)per_layer; b.layers = (int)part[k].layers;
         b.quad = part[k].layers % 4 == 0;
+        b.compact_div = compact_div;
         b.div_group = wf_make_div((uint32_t)(b.quad ? 4 * per_layer : per_layer)); b.div_tiles_x = wf_make_div((uint32_t)p_all.tiles_x);
     }
     // fork: the parts' streams start behind everything the caller's stream holds so far
@@ -651,10 +654,16 @@ static int render_wavefront(rtc_scene *s, const CameraT<float> &camf, const Rend
     for (int k = 0; k < n_parts; ++k) HIP_TRY(launch_wf_primary(s->f32.view, camf, part[k].p, part[k].b, st[k]));
     long long longest = 0;
     for (int k = 0; k < n_parts; ++k) longest = std::max(longest, part[k].iterations);
+    // Compaction points every 2 rounds, and the device squeezes the list there once a sixteenth of it is holes.  (Rounds 1-3 ran every 8 rounds / a quarter,
+    // from the days when extend waves were cheap to leave sparse; with the shading tail in extend a hole costs a lane of a 100-register kernel.  One GPU run,
+    // every / fraction: 8 / 4 -> 2 / 16: final 88.8 -> 83.8 ms, final + earth 154.8 -> 149.7, book1 19.5 -> 17.2, 1M spheres 36.7 -> 35.8;
+    // 1 / 32: 86.7, 153.7, 17.8, 36.3; never squeezing below the threshold (2 / 10^6): 84.3, 150.3, 17.5, 36.2 -- profiles/r03e/compaction_sweep.txt.)
+    long long compact_every = 2;
+    if (const char *e = std::getenv("RTC_WF_COMPACT_EVERY")) compact_every = std::max(1ll, std::atoll(e));   // A/B knob
     for (long long it = 0; it < longest; ++it)                       // round robin, so that the parts' kernels reach the GPU interleaved
         for (int k = 0; k < n_parts; ++k) {
             if (it >= part[k].iterations) continue;
-            if (it && it % 8 == 0) HIP_TRY(launch_wf_compact(part[k].b, st[k]));
+            if (it && it % compact_every == 0) HIP_TRY(launch_wf_compact(part[k].b, st[k]));
             HIP_TRY(launch_wf_bounce(s->f32.view, camf, part[k].p, part[k].b, st[k]));
         }
     // join: the accumulates run in part order (each adds to the same pixels), the last one on the caller's stream

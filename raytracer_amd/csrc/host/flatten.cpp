@@ -266,7 +266,9 @@ struct Builder {
     std::vector<int> &leaf_prims;
     const std::vector<BuildItem> &items;
     std::vector<int> &box_slots;
-    static constexpr int kLeafMax = 2, kBins = 16;
+    static constexpr int kBins = 16;
+    static int leaf_max() { static const int v = [] { const char *e = std::getenv("RTC_BVH_LEAF"); const int k = e ? std::atoi(e) : 2; return k >= 1 && k <= 8 ? k : 2; }(); return v; }   // records per leaf (A/B knob; 2 measured best)
+#define kLeafMax leaf_max()
     struct Child { int child, count; Box box; };
     // Parallel build (build_bvh_parallel): the builder of the top of the tree does not descend into ranges of at most
     // `defer_below` items; it records them and leaves (count = kDeferred, child = index into `deferred`) in the parent.

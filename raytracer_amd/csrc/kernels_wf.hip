@@ -15,7 +15,7 @@
 // A slot owns ONE pixel and walks through its samples in a fixed order, so no atomics touch radiance and the image does
 // not depend on scheduling.  The slot list keeps its order (tile order), which keeps the state accesses coalesced.
 // Same-address atomics cost ~11 ns each on this part (measured: 32 K wave-level appends = 0.37 ms), so nothing on the
-// per-bounce path appends to a shared queue: slots die in place, and the compaction uses one atomic per 1024 entries.
+// per-bounce path appends to a shared queue: slots die in place, and the compaction uses one atomic per 16 K entries.
 // Philox keys are the megakernel's: (pixel, sample, bounce) -- both kernels render the same estimator.
 #include <hip/hip_runtime.h>
 #include <algorithm>
@@ -511,7 +511,7 @@ __global__ void __launch_bounds__(kWfShadeBlock) __attribute__((amdgpu_waves_per
     }
 }
 
-// active[cur][0..n_list) -> active[cur^1][0..live): order kept inside a block, one atomic per block.  Launched at fixed points of the
+// active[cur][0..n_list) -> active[cur^1][0..live): order kept inside a block's 16 K entries, one atomic per block.  Launched at fixed points of the
 // bounce schedule; whether the list is worth squeezing -- 1 / B.compact_div of it holes -- is decided HERE, from the device's own counters,
 // so the host never waits for a count: every block takes the same decision, and k_wf_flip, the next kernel in the stream, takes it
 // once more and makes the new list current.
@@ -519,24 +519,35 @@ __device__ __forceinline__ bool wf_worth_compacting(const WfBuffers &B) {
     const unsigned live = B.counters[WF_LIVE], n_list = B.counters[WF_NLIST];
     return live != 0 && live < n_list - n_list / (unsigned)B.compact_div;
 }
+// A workgroup squeezes kCompactK x 1024 consecutive entries and claims its output range with ONE atomic: a same-address atomic costs ~11 ns
+// and serialises, and with one per 1024 entries a compaction of 11 M entries waited 118 us for its 10,700 atomics -- harmless at a compaction
+// every 8 rounds, 14 % of a render's kernel time at one every 2 (profiles/r03e/final/kernel_stats.csv: 327 us per launch under three-part overlap).
+constexpr int kCompactK = 16;
 __global__ void __launch_bounds__(1024) k_wf_compact(WfBuffers B) {
-    __shared__ unsigned wave_count[16];
+    __shared__ unsigned counts[kCompactK * 16], offs[kCompactK * 16];   // live entries per (chunk, wave), and their exclusive prefix sums
     __shared__ unsigned block_base;
     if (!wf_worth_compacting(B)) return;
     const unsigned n_list = B.counters[WF_NLIST]; const int cur = (int)B.counters[WF_CUR];
-    if (blockIdx.x * blockDim.x >= n_list) return;
-    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
-    const int slot = i < n_list ? B.active[cur][i] : -1;
-    const bool live = slot >= 0;
-    const unsigned long long mask = __builtin_amdgcn_ballot_w64(live);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (lane == 0) wave_count[wave] = (unsigned)__builtin_popcountll(mask);
+    const unsigned first = blockIdx.x * (unsigned)(kCompactK * 1024);
+    if (first >= n_list) return;
+    const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    int slot[kCompactK]; unsigned pos[kCompactK];
+#pragma unroll
+    for (int k = 0; k < kCompactK; ++k) {
+        const unsigned i = first + (unsigned)k * 1024u + tid;
+        slot[k] = i < n_list ? B.active[cur][i] : -1;
+        const unsigned long long mask = __builtin_amdgcn_ballot_w64(slot[k] >= 0);
+        pos[k] = (unsigned)__builtin_popcountll(mask & ((1ull << lane) - 1ull));
+        if (lane == 0) counts[k * 16 + wave] = (unsigned)__builtin_popcountll(mask);
+    }
     __syncthreads();
-    unsigned before = 0, total = 0;
-    for (int w = 0; w < 16; ++w) { const unsigned c = wave_count[w]; before += w < wave ? c : 0u; total += c; }
-    if (threadIdx.x == 0) block_base = total ? atomicAdd(B.counters + WF_CURSOR, total) : 0u;
+    if (tid < kCompactK * 16) { unsigned acc = 0; for (unsigned u = 0; u < tid; ++u) acc += counts[u]; offs[tid] = acc; }   // (every thread of a step reads one address: broadcast)
     __syncthreads();
-    if (live) B.active[cur ^ 1][block_base + before + (unsigned)__builtin_popcountll(mask & ((1ull << lane) - 1ull))] = slot;
+    if (tid == 0) { const unsigned total = offs[kCompactK * 16 - 1] + counts[kCompactK * 16 - 1]; block_base = total ? atomicAdd(B.counters + WF_CURSOR, total) : 0u; }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < kCompactK; ++k)
+        if (slot[k] >= 0) B.active[cur ^ 1][block_base + offs[k * 16 + wave] + pos[k]] = slot[k];
 }
 __global__ void k_wf_flip(WfBuffers B) {
     if (wf_worth_compacting(B)) { B.counters[WF_NLIST] = B.counters[WF_CURSOR]; B.counters[WF_CUR] ^= 1u; }
@@ -628,7 +639,7 @@ hipError_t launch_wf_primary(const SceneT<float> &sc, const CameraT<float> &cam,
     return hipGetLastError();
 }
 hipError_t launch_wf_compact(const WfBuffers &b, hipStream_t stream) {
-    hipLaunchKernelGGL(k_wf_compact, dim3(((unsigned)b.n_slots + 1023) / 1024), dim3(1024), 0, stream, b);
+    hipLaunchKernelGGL(k_wf_compact, dim3(((unsigned)b.n_slots + kCompactK * 1024 - 1) / (kCompactK * 1024)), dim3(1024), 0, stream, b);
     hipLaunchKernelGGL(k_wf_flip, dim3(1), dim3(1), 0, stream, b);
     return hipGetLastError();
 }

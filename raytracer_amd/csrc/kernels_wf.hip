@@ -15,7 +15,7 @@
 // A slot owns ONE pixel and walks through its samples in a fixed order, so no atomics touch radiance and the image does
 // not depend on scheduling.  The slot list keeps its order (tile order), which keeps the state accesses coalesced.
 // Same-address atomics cost ~11 ns each on this part (measured: 32 K wave-level appends = 0.37 ms), so nothing on the
-// per-bounce path appends to a shared queue: slots die in place, and the compaction uses one atomic per 16 K entries.
+// per-bounce path appends to a shared queue: slots die in place, and the compaction uses one atomic per 4 K entries.
 // Philox keys are the megakernel's: (pixel, sample, bounce) -- both kernels render the same estimator.
 #include <hip/hip_runtime.h>
 #include <algorithm>
@@ -428,7 +428,10 @@ __global__ void __launch_bounds__(kWfLdsBlock) __attribute__((amdgpu_waves_per_e
 // wait (and once more at the end): dense waves whatever the density of the list.  The queued entries are counting-sorted in LDS
 // by (material type, texture type) of what they hit, so a wave runs one arm of the material switch instead of all of them.
 // Only slot ids move; no global atomics; the order of the work is a function of the list alone.
-constexpr int kWfShadeBlock = 1024;
+#ifndef RT_WF_SHADE_BLOCK
+#define RT_WF_SHADE_BLOCK 1024
+#endif
+constexpr int kWfShadeBlock = RT_WF_SHADE_BLOCK;
 #ifndef RT_WF_SHADE_WAVES
 #define RT_WF_SHADE_WAVES 5      // resident waves per SIMD (96 VGPRs: no spills in either variant; 6 waves measured the same within 0.5 %)
 #endif
@@ -511,7 +514,7 @@ __global__ void __launch_bounds__(kWfShadeBlock) __attribute__((amdgpu_waves_per
     }
 }
 
-// active[cur][0..n_list) -> active[cur^1][0..live): order kept inside a block's 16 K entries, one atomic per block.  Launched at fixed points of the
+// active[cur][0..n_list) -> active[cur^1][0..live): order kept inside a block's 4 K entries, one atomic per block.  Launched at fixed points of the
 // bounce schedule; whether the list is worth squeezing -- 1 / B.compact_div of it holes -- is decided HERE, from the device's own counters,
 // so the host never waits for a count: every block takes the same decision, and k_wf_flip, the next kernel in the stream, takes it
 // once more and makes the new list current.
@@ -519,35 +522,44 @@ __device__ __forceinline__ bool wf_worth_compacting(const WfBuffers &B) {
     const unsigned live = B.counters[WF_LIVE], n_list = B.counters[WF_NLIST];
     return live != 0 && live < n_list - n_list / (unsigned)B.compact_div;
 }
-// A workgroup squeezes kCompactK x 1024 consecutive entries and claims its output range with ONE atomic: a same-address atomic costs ~11 ns
-// and serialises, and with one per 1024 entries a compaction of 11 M entries waited 118 us for its 10,700 atomics -- harmless at a compaction
-// every 8 rounds, 14 % of a render's kernel time at one every 2 (profiles/r03e/final/kernel_stats.csv: 327 us per launch under three-part overlap).
-constexpr int kCompactK = 16;
-__global__ void __launch_bounds__(1024) k_wf_compact(WfBuffers B) {
-    __shared__ unsigned counts[kCompactK * 16], offs[kCompactK * 16];   // live entries per (chunk, wave), and their exclusive prefix sums
+// A workgroup squeezes kCompactK chunks of kCompactBlock consecutive entries (held in registers) and claims its output range with ONE atomic: a
+// same-address RETURNED atomic costs ~11 ns and serialises, and with one per 1024 entries a compaction of 11 M entries waited 118 us for its
+// 10,700 atomics -- harmless at a compaction every 8 rounds, 14 % of a render's kernel time at one every 2 (profiles/r03e/final/kernel_stats.csv).
+// Small workgroups on purpose: this kernel runs beside the extend launches of the other parts, and a 1024-thread workgroup waits until one CU
+// has 16 wave slots free at once (threads x chunks, one GPU run: 1024 x 16 / 256 x 32 / 256 x 64 / 128 x 32 / 64 x 64 -- 1M spheres 35.3 / 34.7 /
+// 35.3 / 33.9 / 34.3 ms, book1 16.9 / 16.4 / 17.1 / 16.8 / 17.1, final 81.9 / 82.0 / 82.0 / 82.4 / 82.3: profiles/r03e/compaction_sweep.txt).
+#ifndef RT_WF_COMPACT_BLOCK
+#define RT_WF_COMPACT_BLOCK 128
+#endif
+#ifndef RT_WF_COMPACT_K
+#define RT_WF_COMPACT_K 32
+#endif
+constexpr int kCompactK = RT_WF_COMPACT_K, kCompactBlock = RT_WF_COMPACT_BLOCK, kCompactWaves = kCompactBlock / 64;
+__global__ void __launch_bounds__(kCompactBlock) k_wf_compact(WfBuffers B) {
+    __shared__ unsigned counts[kCompactK * kCompactWaves], offs[kCompactK * kCompactWaves];   // live entries per (chunk, wave), and their exclusive prefix sums
     __shared__ unsigned block_base;
     if (!wf_worth_compacting(B)) return;
     const unsigned n_list = B.counters[WF_NLIST]; const int cur = (int)B.counters[WF_CUR];
-    const unsigned first = blockIdx.x * (unsigned)(kCompactK * 1024);
+    const unsigned first = blockIdx.x * (unsigned)(kCompactK * kCompactBlock);
     if (first >= n_list) return;
     const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     int slot[kCompactK]; unsigned pos[kCompactK];
 #pragma unroll
     for (int k = 0; k < kCompactK; ++k) {
-        const unsigned i = first + (unsigned)k * 1024u + tid;
+        const unsigned i = first + (unsigned)(k * kCompactBlock) + tid;
         slot[k] = i < n_list ? B.active[cur][i] : -1;
         const unsigned long long mask = __builtin_amdgcn_ballot_w64(slot[k] >= 0);
         pos[k] = (unsigned)__builtin_popcountll(mask & ((1ull << lane) - 1ull));
-        if (lane == 0) counts[k * 16 + wave] = (unsigned)__builtin_popcountll(mask);
+        if (lane == 0) counts[k * kCompactWaves + wave] = (unsigned)__builtin_popcountll(mask);
     }
     __syncthreads();
-    if (tid < kCompactK * 16) { unsigned acc = 0; for (unsigned u = 0; u < tid; ++u) acc += counts[u]; offs[tid] = acc; }   // (every thread of a step reads one address: broadcast)
+    for (unsigned t = tid; t < kCompactK * kCompactWaves; t += kCompactBlock) { unsigned acc = 0; for (unsigned u = 0; u < t; ++u) acc += counts[u]; offs[t] = acc; }
     __syncthreads();
-    if (tid == 0) { const unsigned total = offs[kCompactK * 16 - 1] + counts[kCompactK * 16 - 1]; block_base = total ? atomicAdd(B.counters + WF_CURSOR, total) : 0u; }
+    if (tid == 0) { const unsigned total = offs[kCompactK * kCompactWaves - 1] + counts[kCompactK * kCompactWaves - 1]; block_base = total ? atomicAdd(B.counters + WF_CURSOR, total) : 0u; }
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < kCompactK; ++k)
-        if (slot[k] >= 0) B.active[cur ^ 1][block_base + offs[k * 16 + wave] + pos[k]] = slot[k];
+        if (slot[k] >= 0) B.active[cur ^ 1][block_base + offs[k * kCompactWaves + wave] + pos[k]] = slot[k];
 }
 __global__ void k_wf_flip(WfBuffers B) {
     if (wf_worth_compacting(B)) { B.counters[WF_NLIST] = B.counters[WF_CURSOR]; B.counters[WF_CUR] ^= 1u; }
@@ -616,7 +628,7 @@ hipError_t launch_wf_bounce(const SceneT<float> &sc, const CameraT<float> &cam, 
     else if (sc.media_kind == 1) hipLaunchKernelGGL((k_wf_extend<1, RTC_KIND_ALL>), dim3(blocks), dim3(kWfExtendBlock), lds, stream, args);
     else hipLaunchKernelGGL((k_wf_extend<2, RTC_KIND_ALL>), dim3(blocks), dim3(kWfExtendBlock), lds, stream, args);
     if (sc.n_general == 0) return hipGetLastError();               // every hit was shaded in extend's tail
-    const dim3 sgrid(std::min((n_max + kWfShadeBlock - 1) / kWfShadeBlock, n_cus));   // persistent: one 1024-thread workgroup per CU
+    const dim3 sgrid(std::min((n_max + kWfShadeBlock - 1) / kWfShadeBlock, n_cus * (1024u / kWfShadeBlock)));   // persistent: 1024 threads per CU
     if (sc.tex_kinds & (1 << RTC_TEX_NOISE)) hipLaunchKernelGGL(k_wf_shade<true>, sgrid, dim3(kWfShadeBlock), 0, stream, args);
     else hipLaunchKernelGGL(k_wf_shade<false>, sgrid, dim3(kWfShadeBlock), 0, stream, args);
     return hipGetLastError();
@@ -639,7 +651,7 @@ hipError_t launch_wf_primary(const SceneT<float> &sc, const CameraT<float> &cam,
     return hipGetLastError();
 }
 hipError_t launch_wf_compact(const WfBuffers &b, hipStream_t stream) {
-    hipLaunchKernelGGL(k_wf_compact, dim3(((unsigned)b.n_slots + kCompactK * 1024 - 1) / (kCompactK * 1024)), dim3(1024), 0, stream, b);
+    hipLaunchKernelGGL(k_wf_compact, dim3(((unsigned)b.n_slots + kCompactK * kCompactBlock - 1) / (kCompactK * kCompactBlock)), dim3(kCompactBlock), 0, stream, b);
     hipLaunchKernelGGL(k_wf_flip, dim3(1), dim3(1), 0, stream, b);
     return hipGetLastError();
 }

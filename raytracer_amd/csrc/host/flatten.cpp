@@ -267,8 +267,14 @@ struct Builder {
     const std::vector<BuildItem> &items;
     std::vector<int> &box_slots;
     static constexpr int kBins = 16;
-    static int leaf_max() { static const int v = [] { const char *e = std::getenv("RTC_BVH_LEAF"); const int k = e ? std::atoi(e) : 2; return k >= 1 && k <= 8 ? k : 2; }(); return v; }   // records per leaf (A/B knob; 2 measured best)
-#define kLeafMax leaf_max()
+    // Records per leaf.  Spheres-only trees: 2 (their leaf test is cheap, and more nodes cost the 1M-sphere scene 3 %); trees with box records, quads,
+    // moving spheres or media: 1 (a wasted leaf test there costs what a node step costs: final scene -3 %).  RTC_BVH_LEAF=n forces one value.
+    int leaf_max = 2;
+    static int leaf_policy(bool spheres_only) {
+        if (const char *e = std::getenv("RTC_BVH_LEAF")) { const int k = std::atoi(e); if (k >= 1 && k <= 8) return k; }
+        return spheres_only ? 2 : 1;
+    }
+#define kLeafMax leaf_max
     struct Child { int child, count; Box box; };
     // Parallel build (build_bvh_parallel): the builder of the top of the tree does not descend into ranges of at most
     // `defer_below` items; it records them and leaves (count = kDeferred, child = index into `deferred`) in the parent.
@@ -359,11 +365,12 @@ struct Builder {
 // 1.6 s -> 0.4 s on 8 cores; the scene files of the two builders are byte-identical (tests/test_bvh_host.py).
 struct BvhPiece { std::vector<BvhNode> nodes; std::vector<int> leaf_prims, box_slots; Builder::Child root; int max_depth = 0; };
 Builder::Child build_bvh_parallel(const std::vector<Box> &item_boxes, const std::vector<BuildItem> &items, std::vector<int> &idx, int threads,
-                                  std::vector<BvhNode> &nodes, std::vector<int> &leaf_prims, std::vector<int> &box_slots, int &max_depth) {
+                                  std::vector<BvhNode> &nodes, std::vector<int> &leaf_prims, std::vector<int> &box_slots, int &max_depth, int leaf_max) {
     const int n = (int)idx.size();
     std::vector<BvhNode> top_nodes; std::vector<int> top_leaves, top_boxes;   // the top builder makes no leaves: every small range is deferred
     Builder top{item_boxes, idx, top_nodes, top_leaves, items, top_boxes};
-    top.defer_below = std::max(n / 256, Builder::kLeafMax);
+    top.leaf_max = leaf_max;
+    top.defer_below = std::max(n / 256, leaf_max);
     const Builder::Child top_root = top.build(0, n);
     std::vector<BvhPiece> pieces(top.deferred.size());
     std::atomic<size_t> next{0};
@@ -371,6 +378,7 @@ Builder::Child build_bvh_parallel(const std::vector<Box> &item_boxes, const std:
         for (size_t i = next.fetch_add(1); i < pieces.size(); i = next.fetch_add(1)) {
             BvhPiece &pc = pieces[i]; const Builder::Deferred &d = top.deferred[i];
             Builder b{item_boxes, idx, pc.nodes, pc.leaf_prims, items, pc.box_slots};
+            b.leaf_max = leaf_max;
             pc.nodes.reserve((size_t)(d.hi - d.lo));
             pc.root = b.build(d.lo, d.hi, d.depth); pc.max_depth = b.max_depth;
         }
@@ -895,10 +903,14 @@ bool flatten_scene(const hittable_list *world, const hittable_list *lights, cons
         int threads = (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
         if (const char *e = std::getenv("RTC_BUILD_THREADS")) threads = std::max(1, std::atoi(e));
         Builder::Child root; int max_depth = 0;
+        bool spheres_only = true;
+        for (const BuildItem &it : items) spheres_only = spheres_only && !it.is_box && out.prims[it.prim].type == RTC_PRIM_SPHERE;
+        const int leaf_max = Builder::leaf_policy(spheres_only);
         if (threads > 1 && (items.size() >= 50000 || std::getenv("RTC_BUILD_THREADS")))
-            root = build_bvh_parallel(item_boxes, items, idx, threads, out.nodes, out.leaf_prims, out.box_slots, max_depth);
+            root = build_bvh_parallel(item_boxes, items, idx, threads, out.nodes, out.leaf_prims, out.box_slots, max_depth, leaf_max);
         else {
             Builder b{item_boxes, idx, out.nodes, out.leaf_prims, items, out.box_slots};
+            b.leaf_max = leaf_max;
             out.nodes.reserve(out.prims.size());
             root = b.build(0, (int)idx.size()); max_depth = b.max_depth;
         }

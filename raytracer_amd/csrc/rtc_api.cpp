@@ -52,6 +52,7 @@ struct DevBuf {
 template <typename R> struct DeviceTables {
     DevBuf prims, bprims, ops, chains, materials, textures, lights, perlin_vec, perlin_perm, images, image_data, nodes, leaf_prims, bleaves, leaf_shade, ref_steps, ref_boxes;
     SceneT<R> view;
+    int root_child0 = 0;   // child0 of node 0 as uploaded (a one-leaf tree starts its traversals at that run, and the device copy may have packed it)
     bool ready = false;
 };
 
@@ -88,9 +89,28 @@ template <typename R> hipError_t upload_tables(const FlatScene &fs, DeviceTables
                 };
                 for (int a = 0; a < 3; a++) { conv1(n.lo0[a], n.hi0[a], o.c0[a], o.h0[a]); conv1(n.lo1[a], n.hi1[a], o.c1[a], o.h1[a]); }
             }
+            // Leaf runs of two plain spheres become ONE record on the device (RTC_LEAF_PAIR: the second sphere rides in d[4..7] of the first, the run's
+            // reference shrinks to one record): one fetch and one trip of the traversal instead of two.  The host tables -- scene files, dumps, the
+            // validator -- keep one record per slot; slot numbers, leaf_prims and leaf_shade are untouched.  RTC_LEAF_PAIRS=0: off (A/B, tests).
+            std::vector<BLeaf> bl = fs.bleaves;
+            bool pairs = true;
+            if (const char *e = std::getenv("RTC_LEAF_PAIRS")) pairs = std::atoi(e) != 0;
+            auto plain_sphere = [&](int s) { return s >= 0 && s < (int)bl.size() && (bl[(size_t)s].meta & 3u) == RTC_PRIM_SPHERE && !(bl[(size_t)s].meta & (RTC_LEAF_BOX | RTC_LEAF_PAIR)); };
+            auto pack = [&](int &child, int &count) {
+                if (!pairs || count != 2 || child >= 0) return;
+                const int first = (~child) >> 3;
+                if (((~child) & 7) != 1 || !plain_sphere(first) || !plain_sphere(first + 1)) return;
+                BLeaf &a = bl[(size_t)first]; const BLeaf &b = fs.bleaves[(size_t)first + 1];
+                for (int k = 0; k < 4; k++) a.d[4 + k] = b.d[k];
+                a.meta |= RTC_LEAF_PAIR;
+                child = rtc_leaf_ref(first, 1); count = 1;
+            };
+            for (BvhNodeCH &o : ch) { pack(o.child0, o.count0); pack(o.child1, o.count1); }
             UP(nodes, ch);
+            UP(bleaves, bl);
+            dt.root_child0 = ch.empty() ? 0 : ch[0].child0;
         }
-        UP(bleaves, fs.bleaves); UP(leaf_shade, fs.leaf_shade);
+        UP(leaf_shade, fs.leaf_shade);
     }
 #undef UP
     SceneT<R> &v = dt.view;
@@ -106,7 +126,7 @@ template <typename R> hipError_t upload_tables(const FlatScene &fs, DeviceTables
     v.bleaves = (const BLeaf *)dt.bleaves.p; v.leaf_shade = (const SmallShade *)dt.leaf_shade.p;
     v.ref_steps = (const RefStep *)dt.ref_steps.p; v.ref_boxes = (const double *)dt.ref_boxes.p;
     v.n_ref_steps = with_ref_steps ? (int)fs.ref_steps.size() : 0;
-    v.bvh_root = (fs.nodes.size() == 1 && fs.nodes[0].child1 == RTC_BVH_EMPTY) ? fs.nodes[0].child0 : 0;
+    v.bvh_root = (fs.nodes.size() == 1 && fs.nodes[0].child1 == RTC_BVH_EMPTY) ? (with_ref_steps ? fs.nodes[0].child0 : dt.root_child0) : 0;
     v.bvh_stack = fs.bvh_depth < 1 ? 1 : fs.bvh_depth;   // one entry per level; flatten / load refuse trees deeper than RTC_BVH_MAX_DEPTH: nothing is clamped here
     v.n_media = fs.n_media;
     v.n_bleaves = (int)fs.bleaves.size();

@@ -61,7 +61,8 @@ inline int rtc_leaf_ref(int first, int count) { return ~((first << 3) | (count -
 //            any other boundary: nothing here, the record is prims[leaf_prims[s]]
 // meta: bits 0-1 RTC_PRIM_*, bits 2-3 rect axis, bits 4-6 material type, bit 7 sphere-bounded medium, bits 8-9 texture
 //       type of the material (material + texture type = the ray regrouping key of the wavefront shade stage)
-enum { RTC_LEAF_BOX = 1u << 10 };
+enum { RTC_LEAF_BOX = 1u << 10,
+       RTC_LEAF_PAIR = 1u << 11 };   // DEVICE tables only (rtc_api.cpp upload_tables): this sphere record also holds the sphere of the next slot in d[4..7]
 struct alignas(64) BLeaf { float d[15]; uint32_t meta; };
 
 // One step of the REFERENCE's own traversal -- the hittable_list scan (hittable_list.c:125-143) with bvh_node_hit's

@@ -1245,6 +1245,30 @@ def test_light_pdf_fused_into_the_intersection_equals_the_light_loop(gpu, monkey
         assert rel <= 2e-5
 
 
+def test_packed_sphere_pairs_change_nothing(gpu, monkeypatch):
+    """A BVH leaf run of two plain spheres is ONE 64-byte record in the device tables (rtc_api.cpp upload_tables, RTC_LEAF_PAIR: the second sphere
+    rides in the first one's record, the traversal tests both in one trip); RTC_LEAF_PAIRS=0 at scene build keeps one record per slot.  Same
+    tests in the same order with the same tie rule: accumulators bit-identical and ray counts equal -- through the LDS-table extend (book1),
+    the plain extend with the per-wave camera pass (the million generator at 80 x 80, also with the LDS tables off) and a mixed scene whose
+    tree holds spheres next to boxes and moving spheres (book2_random)."""
+    for name, arg, W, H, spp, lds in (("book1", 0, 240, 160, 48, None), ("million", 80, 240, 136, 32, None), ("million", 80, 240, 136, 32, "0"), ("book2_random", 0, 240, 136, 32, None)):
+        out = []
+        for pairs in ("0", "1"):
+            monkeypatch.setenv("RTC_LEAF_PAIRS", pairs)
+            if lds is None: monkeypatch.delenv("RTC_WF_LDS_TABLES", raising=False)
+            else: monkeypatch.setenv("RTC_WF_LDS_TABLES", lds)
+            sc, cam, view = gpu.build_named_scene(name, arg=arg, aspect=1.5)
+            try:
+                acc, st = sc.render(cam, gpu.Settings(W, H, spp, view.max_depth, view.integrator, seed=21, kernel=3))
+                assert st["kernel_used"] == 3
+                out.append((acc.copy(), st["rays"]))
+            finally:
+                sc.close()
+        monkeypatch.delenv("RTC_LEAF_PAIRS", raising=False); monkeypatch.delenv("RTC_WF_LDS_TABLES", raising=False)
+        assert out[0][1] == out[1][1] and out[0][1] > W * H * spp, name
+        assert np.array_equal(out[0][0], out[1][0]) and out[0][0][..., :3].sum() > 0, name
+
+
 def test_extend_from_lds_tables_equals_the_plain_extend(gpu, monkeypatch):
     """Small trees without media (book1: 281 nodes + 486 leaf records) are traversed from a copy of the node and leaf tables in LDS, with
     16-bit stack entries (k_wf_extend_lds, kernels_wf.hip); RTC_WF_LDS_TABLES=0 keeps the plain kernel.  Same traversal, same visiting

@@ -365,13 +365,15 @@ struct Builder {
 // 1.6 s -> 0.4 s on 8 cores; the scene files of the two builders are byte-identical (tests/test_bvh_host.py).
 struct BvhPiece { std::vector<BvhNode> nodes; std::vector<int> leaf_prims, box_slots; Builder::Child root; int max_depth = 0; };
 Builder::Child build_bvh_parallel(const std::vector<Box> &item_boxes, const std::vector<BuildItem> &items, std::vector<int> &idx, int threads,
-                                  std::vector<BvhNode> &nodes, std::vector<int> &leaf_prims, std::vector<int> &box_slots, int &max_depth, int leaf_max) {
-    const int n = (int)idx.size();
+                                  std::vector<BvhNode> &nodes, std::vector<int> &leaf_prims, std::vector<int> &box_slots, int &max_depth, int leaf_max,
+                                  int first = 0, int depth0 = 1) {
+    // items idx[first ..): what lies before `first` (an item hung off the root by the caller) already has its node and leaf slots in the tables
+    const int n = (int)idx.size() - first;
     std::vector<BvhNode> top_nodes; std::vector<int> top_leaves, top_boxes;   // the top builder makes no leaves: every small range is deferred
     Builder top{item_boxes, idx, top_nodes, top_leaves, items, top_boxes};
     top.leaf_max = leaf_max;
     top.defer_below = std::max(n / 256, leaf_max);
-    const Builder::Child top_root = top.build(0, n);
+    const Builder::Child top_root = top.build(first, first + n, depth0);
     std::vector<BvhPiece> pieces(top.deferred.size());
     std::atomic<size_t> next{0};
     auto worker = [&]() {
@@ -390,7 +392,7 @@ Builder::Child build_bvh_parallel(const std::vector<Box> &item_boxes, const std:
     max_depth = top.max_depth;
     for (const BvhPiece &pc : pieces) max_depth = std::max(max_depth, pc.max_depth);
     // splice, in pre-order
-    nodes.clear(); leaf_prims.clear(); box_slots.clear();
+    if (first == 0) { nodes.clear(); leaf_prims.clear(); box_slots.clear(); }
     nodes.reserve((size_t)n); leaf_prims.reserve((size_t)n);
     auto shift_ref = [](int child, int count, int node_base, int leaf_base) {   // a child reference of a piece, moved to its place in the whole
         if (count == 0) return child + node_base;
@@ -414,8 +416,9 @@ Builder::Child build_bvh_parallel(const std::vector<Box> &item_boxes, const std:
     // explicit stack instead of recursion: (top node, its index in the whole, which child comes next)
     struct Frame { int top, out, side; };
     std::vector<Frame> st;
+    const int out0 = (int)nodes.size();
     nodes.push_back(top_nodes[(size_t)top_root.child]);
-    st.push_back({top_root.child, 0, 0});
+    st.push_back({top_root.child, out0, 0});
     while (!st.empty()) {
         Frame &f = st.back();
         if (f.side == 2) { st.pop_back(); continue; }
@@ -436,7 +439,7 @@ Builder::Child build_bvh_parallel(const std::vector<Box> &item_boxes, const std:
             st.push_back({child, me, 0});
         }
     }
-    Builder::Child root = top_root; root.child = 0;
+    Builder::Child root = top_root; root.child = out0;
     return root;
 }
 
@@ -906,13 +909,50 @@ bool flatten_scene(const hittable_list *world, const hittable_list *lights, cons
         bool spheres_only = true;
         for (const BuildItem &it : items) spheres_only = spheres_only && !it.is_box && out.prims[it.prim].type == RTC_PRIM_SPHERE;
         const int leaf_max = Builder::leaf_policy(spheres_only);
+        // One item whose box is (nearly) the whole scene's -- the global fog of the Book-2 final scene, a sphere of r = 5000 around a 2000-unit
+        // scene -- must not be sorted into the tree by its centroid: every ancestor it gets inherits its box, and every ray then walks that
+        // chain of always-hit nodes down to it (final scene: node 201, a dozen levels deep).  It becomes a child of the ROOT, the tree is built
+        // over the rest (tight boxes), and the traversals test it ahead of their loop (rtc_api.cpp upload_tables, SceneT::pre_slot).
+        // RTC_BVH_HUGE=0: off (A/B, tests).
+        int huge = -1;
+        bool extract = idx.size() >= 8;
+        if (const char *e = std::getenv("RTC_BVH_HUGE")) extract = extract && std::atoi(e) != 0;
+        if (extract) {
+            Box all = box_empty(); for (const Box &x : item_boxes) box_merge(all, x);
+            int n_huge = 0;
+            for (size_t i = 0; i < item_boxes.size(); i++)
+                if (Builder::area(item_boxes[i]) >= 0.5 * Builder::area(all)) { ++n_huge; huge = (int)i; }
+            if (n_huge != 1) huge = -1;
+            if (huge >= 0) {                                      // ... and it must dwarf the rest: the others' common box at most a quarter of its area
+                Box rest = box_empty(); for (size_t i = 0; i < item_boxes.size(); i++) if ((int)i != huge) box_merge(rest, item_boxes[i]);
+                if (!(Builder::area(rest) <= 0.25 * Builder::area(item_boxes[(size_t)huge]))) huge = -1;
+            }
+        }
+        Builder b{item_boxes, idx, out.nodes, out.leaf_prims, items, out.box_slots};
+        b.leaf_max = leaf_max;
+        int first = 0, depth0 = 1, root_node = -1;
+        Builder::Child huge_leaf;
+        if (huge >= 0) {
+            std::swap(idx[0], idx[(size_t)huge]);                 // (idx is the identity here)
+            root_node = (int)out.nodes.size();
+            out.nodes.push_back(BvhNode());
+            huge_leaf = b.make_leaf(0, 1, item_boxes[(size_t)idx[0]]);
+            first = 1; depth0 = 2;
+        }
         if (threads > 1 && (items.size() >= 50000 || std::getenv("RTC_BUILD_THREADS")))
-            root = build_bvh_parallel(item_boxes, items, idx, threads, out.nodes, out.leaf_prims, out.box_slots, max_depth, leaf_max);
+            root = build_bvh_parallel(item_boxes, items, idx, threads, out.nodes, out.leaf_prims, out.box_slots, max_depth, leaf_max, first, depth0);
         else {
-            Builder b{item_boxes, idx, out.nodes, out.leaf_prims, items, out.box_slots};
-            b.leaf_max = leaf_max;
             out.nodes.reserve(out.prims.size());
-            root = b.build(0, (int)idx.size()); max_depth = b.max_depth;
+            root = b.build(first, (int)idx.size(), depth0); max_depth = b.max_depth;
+        }
+        if (huge >= 0) {
+            const Builder::Child l = huge_leaf, r = root;
+            BvhNode &nd = out.nodes[(size_t)root_node];
+            for (int a = 0; a < 3; a++) { nd.lo0[a] = Builder::down(l.box.lo[a]); nd.hi0[a] = Builder::up(l.box.hi[a]); nd.lo1[a] = Builder::down(r.box.lo[a]); nd.hi1[a] = Builder::up(r.box.hi[a]); }
+            nd.child0 = rtc_leaf_ref(l.child, l.count); nd.count0 = l.count;
+            nd.child1 = r.count > 0 ? rtc_leaf_ref(r.child, r.count) : r.child; nd.count1 = r.count;
+            root.child = root_node; root.count = 0; root.box = l.box; box_merge(root.box, r.box);
+            max_depth = std::max(max_depth, 2);
         }
         lap("bvh build");
         if (root.count > 0) {   // degenerate: everything fell into one leaf -> wrap it in a node

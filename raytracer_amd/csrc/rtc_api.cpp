@@ -52,6 +52,7 @@ struct DevBuf {
 template <typename R> struct DeviceTables {
     DevBuf prims, bprims, ops, chains, materials, textures, lights, perlin_vec, perlin_perm, images, image_data, nodes, leaf_prims, bleaves, leaf_shade, ref_steps, ref_boxes;
     SceneT<R> view;
+    int pre_slot = -1, pre_root = 0;   // SceneT::pre_slot and the root's other child, where the traversals then start
     int root_child0 = 0;   // child0 of node 0 as uploaded (a one-leaf tree starts its traversals at that run, and the device copy may have packed it)
     bool ready = false;
 };
@@ -109,6 +110,25 @@ template <typename R> hipError_t upload_tables(const FlatScene &fs, DeviceTables
             UP(nodes, ch);
             UP(bleaves, bl);
             dt.root_child0 = ch.empty() ? 0 : ch[0].child0;
+            // A one-record leaf run that hangs off the ROOT: flatten.cpp puts an item there whose box is (nearly) the whole scene's -- the global fog of the
+            // Book-2 final scene (r = 5000 around everything), the ground sphere of the Book-1 scenes -- so nearly every ray meets it.  The traversals test
+            // that record ahead of their loop and start at the root's other child (SceneT::pre_slot / bvh_root): one node step and one trip fewer per ray, a
+            // tmax from the first instruction on, and node 0 is never visited.  Device view only; RTC_PRE_LEAF=0: off (A/B, tests).
+            dt.pre_slot = -1; dt.pre_root = 0;
+            bool pre = true;
+            if (const char *e = std::getenv("RTC_PRE_LEAF")) pre = std::atoi(e) != 0;
+            if (pre && ch.size() > 1) {
+                const BvhNodeCH &r0 = ch[0];
+                for (int side = 0; side < 2 && dt.pre_slot < 0; side++) {
+                    const int child = side ? r0.child1 : r0.child0, other = side ? r0.child0 : r0.child1;
+                    const float *oh = side ? r0.h0 : r0.h1;
+                    if (child >= 0 || child == RTC_BVH_EMPTY || other == RTC_BVH_EMPTY || ((~child) & 7) != 0) continue;   // a run of exactly one record
+                    const int slot = (~child) >> 3;
+                    if (slot < 0 || slot >= (int)bl.size()) continue;
+                    if (!(oh[0] >= 0.0f) || (bl[(size_t)slot].meta & RTC_LEAF_BOX)) continue;   // (a box record owns six slots: left in the tree)
+                    dt.pre_slot = slot; dt.pre_root = other;
+                }
+            }
         }
         UP(leaf_shade, fs.leaf_shade);
     }
@@ -127,6 +147,8 @@ template <typename R> hipError_t upload_tables(const FlatScene &fs, DeviceTables
     v.ref_steps = (const RefStep *)dt.ref_steps.p; v.ref_boxes = (const double *)dt.ref_boxes.p;
     v.n_ref_steps = with_ref_steps ? (int)fs.ref_steps.size() : 0;
     v.bvh_root = (fs.nodes.size() == 1 && fs.nodes[0].child1 == RTC_BVH_EMPTY) ? (with_ref_steps ? fs.nodes[0].child0 : dt.root_child0) : 0;
+    v.pre_slot = -1;
+    if (!with_ref_steps && dt.pre_slot >= 0) { v.pre_slot = dt.pre_slot; v.bvh_root = dt.pre_root; }
     v.bvh_stack = fs.bvh_depth < 1 ? 1 : fs.bvh_depth;   // one entry per level; flatten / load refuse trees deeper than RTC_BVH_MAX_DEPTH: nothing is clamped here
     v.n_media = fs.n_media;
     v.n_bleaves = (int)fs.bleaves.size();

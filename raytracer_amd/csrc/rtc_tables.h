@@ -86,6 +86,8 @@ template <typename R> struct SceneT {
     const BvhNodeCH *nodes;  const int *leaf_prims; int n_nodes;   // n_nodes == 0: brute-force loop over prims
     const BLeaf *bleaves;                                          // FP32 production BVH only (NULL in the FP64 tables)
     const struct SmallShade *leaf_shade;                           // per leaf slot: everything shading needs of a resolved leaf, one 48-byte read
+    int pre_slot;            // >= 0: a sphere-bounded medium that hangs off the tree's root and encloses the rest of it (the global fog of the Book-2 final scene) --
+                             // every ray meets it, so a traversal tests that leaf record FIRST and starts at the root's other child (rtc_api.cpp upload_tables)
     int bvh_root;            // where a traversal starts: node 0, or the leaf run itself when the whole scene is one leaf (its node's second child is RTC_BVH_EMPTY and its box is never tested)
     int bvh_stack;           // entries the traversal stack needs: the levels of the binary tree
     const RefStep *ref_steps; const double *ref_boxes; int n_ref_steps;   // FP64 check path; boxes = min xyz, max xyz

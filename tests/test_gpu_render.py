@@ -1269,6 +1269,43 @@ def test_packed_sphere_pairs_change_nothing(gpu, monkeypatch):
         assert np.array_equal(out[0][0], out[1][0]) and out[0][0][..., :3].sum() > 0, name
 
 
+@pytest.mark.parametrize("name,W,H,spp", [("final", 256, 256, 32), ("final_earth", 240, 136, 24), ("book1", 240, 160, 32), ("book2_random", 240, 136, 24)])
+def test_scene_sized_item_at_the_root_changes_nothing(gpu, monkeypatch, name, W, H, spp):
+    """An item whose box is (nearly) the whole scene's -- the global fog of the final scene (r = 5000 around a 2000-unit scene), the ground sphere
+    of the Book-1 scenes -- is hung off the ROOT by the builder instead of being sorted into the tree by its centroid (flatten.cpp; RTC_BVH_HUGE=0
+    is the old tree, where every ancestor of the fog inherited its box), and the traversals test that one record ahead of their loop and start
+    at the root's other child (rtc_api.cpp upload_tables, SceneT::pre_slot; RTC_PRE_LEAF=0: the record is met through node 0 like any other).
+    Other visiting order, same closest hits (ties go to the later primitive): the pre-test never changes a bit, and neither does the other tree on
+    scenes without media; with media the other tree renumbers the leaf slots a medium's free-flight draws are keyed by -- same estimator, other
+    random numbers -- so there the two trees are compared statistically."""
+    out = []
+    for huge, pre in (("0", "0"), ("1", "0"), ("0", "1"), ("1", "1")):
+        monkeypatch.setenv("RTC_BVH_HUGE", huge); monkeypatch.setenv("RTC_PRE_LEAF", pre)
+        sc, cam, view = gpu.build_named_scene(name, aspect=W / H)
+        try:
+            acc, st = sc.render(cam, gpu.Settings(W, H, spp, view.max_depth, view.integrator, seed=17, kernel=3))
+            assert st["kernel_used"] == 3
+            out.append((acc.copy(), st["rays"], sc.bvh_info()["depth"]))
+        finally:
+            sc.close()
+    monkeypatch.delenv("RTC_BVH_HUGE", raising=False); monkeypatch.delenv("RTC_PRE_LEAF", raising=False)
+    # the pre-test alone never changes a bit (out: (huge, pre) = (0, 0), (1, 0), (0, 1), (1, 1))
+    assert out[2][1] == out[0][1] and np.array_equal(out[2][0], out[0][0]), name
+    assert out[3][1] == out[1][1] and np.array_equal(out[3][0], out[1][0]), name
+    if name.startswith("final"):
+        # the other tree numbers the leaf slots differently, and a medium's free-flight draw is keyed by its slot: other random numbers, same estimator
+        # (the full-size comparison with the oracle, test_full_size_final_1024_against_the_oracle_at_full_size, runs on the new tree)
+        a, b = out[1][0][..., :3].astype(np.float64) / spp, out[0][0][..., :3].astype(np.float64) / spp
+        blocks = lambda x: np.clip(x, 0, 1)[:H // 8 * 8, :W // 8 * 8].reshape(H // 8, 8, W // 8, 8, 3).mean(axis=(1, 3))
+        rmse = np.sqrt(((blocks(a) - blocks(b)) ** 2).mean())
+        print(name, "other slot numbering: 8x8-block rmse", rmse, "rays", out[1][1], out[0][1])
+        assert rmse <= 0.02 and abs(out[1][1] - out[0][1]) <= 0.002 * out[0][1]
+        assert abs(np.clip(a, 0, 1).mean() - np.clip(b, 0, 1).mean()) <= 0.01 * np.clip(b, 0, 1).mean()
+    else:
+        assert out[1][1] == out[0][1] and np.array_equal(out[1][0], out[0][0]), name
+    assert out[0][0][..., :3].sum() > 0 and out[0][1] > W * H * spp
+
+
 def test_extend_from_lds_tables_equals_the_plain_extend(gpu, monkeypatch):
     """Small trees without media (book1: 281 nodes + 486 leaf records) are traversed from a copy of the node and leaf tables in LDS, with
     16-bit stack entries (k_wf_extend_lds, kernels_wf.hip); RTC_WF_LDS_TABLES=0 keeps the plain kernel.  Same traversal, same visiting

@@ -69,10 +69,11 @@ PEAK_L2_GBS = 34500.0             # MI355X_MICROARCH.md: 8 x 4 MiB L2, ~34.5 TB/
 # (profiles/r03d/final: extend active-lane 0.19, wait 0.59) -> "valu"; the 1M-sphere tree (105 MB) is served by L2 + Infinity Cache
 # (profiles/r03d/million: TCC hit rate 0.61) -> "l2", with the L2 requests counted by rocprofv3 beside the algorithmic bytes.
 SCENE_MODEL = {
-    # (final / final_earth: trees with one record per leaf since the end of round 3 -- 1,406 nodes instead of 832; the round-2 probe counts 10.4 + 3.3 and
-    # 10.0 + 2.7 scaled by the host traversal model's ratio between the two trees, tools/exp/sim_traversal.py: node steps x 1.095, leaf steps x 0.6)
-    "final":       dict(node_steps=11.4, leaf_steps=2.0, leaf_flop=22, other_flop=128.1, bound="valu"),
-    "final_earth": dict(node_steps=11.0, leaf_steps=1.6, leaf_flop=22, other_flop=119.4, bound="valu"),
+    # (final / final_earth: trees with one record per leaf and the global fog hung off the root since the end of round 3 -- the round-2 probe counts
+    # 10.4 + 3.3 and 10.0 + 2.7 scaled by the host traversal model's ratio between the old and the new tree, tools/exp/sim_traversal.py: 15.4 -> 12.2 trips
+    # per ray of the model's ray mix, 83 % of them node steps; the pre-tested fog record counts as a leaf step)
+    "final":       dict(node_steps=9.0, leaf_steps=1.9, leaf_flop=22, other_flop=128.1, bound="valu"),
+    "final_earth": dict(node_steps=8.7, leaf_steps=1.5, leaf_flop=22, other_flop=119.4, bound="valu"),
     "book1":       dict(node_steps=9.5, leaf_steps=2.4, leaf_flop=26, other_flop=32.8, bound="valu"),
     "million":     dict(node_steps=23.6, leaf_steps=2.7, leaf_flop=26, other_flop=32.8, bound="l2"),
 }

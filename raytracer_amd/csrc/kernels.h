@@ -68,6 +68,7 @@ struct WfBuffers {
     int phit_k;                       // 0: no camera rays traced ahead (every sample's first ray goes through the slot list)
     WfDiv div_layers;                 // (sample - s_begin) / layers = which of the slot's samples
     int compact_div;                  // k_wf_compact squeezes the list when more than 1 / compact_div of it is holes
+    int noise_lds_slots;              // k_wf_shade keeps the tables of up to this many noise textures in LDS (2; 0 = read them from memory: RTC_WF_NOISE_LDS=0, an A/B knob)
 };
 size_t wf_bytes_per_slot();
 size_t wf_stats_bytes();

@@ -435,6 +435,10 @@ constexpr int kWfShadeBlock = RT_WF_SHADE_BLOCK;
 #ifndef RT_WF_SHADE_WAVES
 #define RT_WF_SHADE_WAVES 5      // resident waves per SIMD (96 VGPRs: no spills in either variant; 6 waves measured the same within 0.5 %)
 #endif
+// The turbulence of a noise texture is 7 octaves x 8 lattice corners x (3 permutation + 3 vector words): 210 dependent-pair table loads per hit
+// from 6 KB of tables.  The workgroup keeps the tables of up to kWfShadeNoiseSlots noise textures in LDS and hands the shading code
+// generic pointers to them (a scene with more noise textures reads them from memory as before).
+constexpr int kWfShadeNoiseSlots = 2;
 // The scan takes FOUR keys per thread and trip (one dword load, one barrier per 4096 list entries; the next trip's keys are requested
 // before this trip's are looked at): with one key per thread and two barriers per 1024 entries the scan of a sparse list -- 2-3 % parked --
 // was most of this kernel's time.  The queue is a ring of 8192 entries (list position + key) in LDS.
@@ -448,7 +452,13 @@ __global__ void __launch_bounds__(kWfShadeBlock) __attribute__((amdgpu_waves_per
     __shared__ unsigned char q_key[QCAP];
     __shared__ unsigned wave_count[N / 64], key_count[32], key_start[32];
     __shared__ unsigned sorted_index[N];
+    __shared__ float noise_vec[NOISE ? 768 * kWfShadeNoiseSlots : 1];
+    __shared__ int noise_perm[NOISE ? 768 * kWfShadeNoiseSlots : 1];
     const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const bool noise_in_lds = NOISE && a.sc.n_perlin <= (a.B.noise_lds_slots < kWfShadeNoiseSlots ? a.B.noise_lds_slots : kWfShadeNoiseSlots);
+    if (noise_in_lds) {                                              // (visible to every wave behind the first barrier below)
+        for (unsigned t = tid; t < 768u * (unsigned)a.sc.n_perlin; t += N) { noise_vec[t] = a.sc.perlin_vec[t]; noise_perm[t] = a.sc.perlin_perm[t]; }
+    }
     const unsigned n_chunks = (n_list + KPT * N - 1) / (KPT * N);
     const unsigned *const key_words = reinterpret_cast<const unsigned *>(B.key);
     const unsigned done4 = 0x01010101u * (unsigned)RTC_WF_KEY_DONE;
@@ -503,7 +513,11 @@ __global__ void __launch_bounds__(kWfShadeBlock) __attribute__((amdgpu_waves_per
                 const float2 hh = t.B.hit[slot];
                 SmallShade none; none.meta = 0;
                 unsigned char no_key = 0;
-                died = wf_shade_entry<NOISE, true>(t.sc, t.cam, t.P, t.B, slot, px, py, o, d, tm, hh.x, __float_as_int(hh.y), none, no_key);
+                if (noise_in_lds) {                                  // (its own copy of the shading code: the compiler then knows the tables' address space and reads them with ds_read)
+                    SceneT<float> sc = t.sc; sc.perlin_vec = noise_vec; sc.perlin_perm = noise_perm;
+                    died = wf_shade_entry<NOISE, true>(sc, t.cam, t.P, t.B, slot, px, py, o, d, tm, hh.x, __float_as_int(hh.y), none, no_key);
+                }
+                else died = wf_shade_entry<NOISE, true>(t.sc, t.cam, t.P, t.B, slot, px, py, o, d, tm, hh.x, __float_as_int(hh.y), none, no_key);
                 if (died) t.B.active[cur][i] = -1;                   // stays in the list as a hole until the next compaction
             }
             wave_count_sub(B.counters + 0, died);
@@ -628,7 +642,8 @@ hipError_t launch_wf_bounce(const SceneT<float> &sc, const CameraT<float> &cam, 
     else if (sc.media_kind == 1) hipLaunchKernelGGL((k_wf_extend<1, RTC_KIND_ALL>), dim3(blocks), dim3(kWfExtendBlock), lds, stream, args);
     else hipLaunchKernelGGL((k_wf_extend<2, RTC_KIND_ALL>), dim3(blocks), dim3(kWfExtendBlock), lds, stream, args);
     if (sc.n_general == 0) return hipGetLastError();               // every hit was shaded in extend's tail
-    const dim3 sgrid(std::min((n_max + kWfShadeBlock - 1) / kWfShadeBlock, n_cus * (1024u / kWfShadeBlock)));   // persistent: 1024 threads per CU
+    static const unsigned shade_wgs = [] { const char *e = std::getenv("RTC_WF_SHADE_WGS"); const int v = e ? std::atoi(e) : 0; return v > 0 ? (unsigned)v : n_cus * (1024u / kWfShadeBlock); }();
+    const dim3 sgrid(std::min((n_max + kWfShadeBlock - 1) / kWfShadeBlock, shade_wgs));   // persistent: 1024 threads per CU
     if (sc.tex_kinds & (1 << RTC_TEX_NOISE)) hipLaunchKernelGGL(k_wf_shade<true>, sgrid, dim3(kWfShadeBlock), 0, stream, args);
     else hipLaunchKernelGGL(k_wf_shade<false>, sgrid, dim3(kWfShadeBlock), 0, stream, args);
     return hipGetLastError();

@@ -155,6 +155,7 @@ template <typename R> hipError_t upload_tables(const FlatScene &fs, DeviceTables
     v.n_general = 0; for (const SmallShade &sh : fs.leaf_shade) v.n_general += (sh.meta & RTC_SF_GENERAL) != 0;
     v.leaf_kinds = fs.leaf_kinds;
     v.tex_kinds = 0; for (const auto &t : fs.textures) v.tex_kinds |= 1 << t.type;
+    v.n_perlin = (int)(fs.perlin_perm.size() / 768);
     v.media_kind = fs.n_media ? (fs.nodes.empty() ? 2 : fs.media_kind) : 0;
     for (int i = 0; i < 3; i++) v.background[i] = (R)fs.background[i];
     dt.ready = true;
@@ -685,6 +686,7 @@ static int render_wavefront(rtc_scene *s, const CameraT<float> &camf, const Rend
         b.n_slots = (int)n; b.slots_per_layer = (int)per_layer; b.layers = (int)part[k].layers;
         b.quad = part[k].layers % 4 == 0;
         b.compact_div = compact_div;
+        b.noise_lds_slots = (std::getenv("RTC_WF_NOISE_LDS") && std::atoi(std::getenv("RTC_WF_NOISE_LDS")) == 0) ? 0 : 2;
         b.div_group = wf_make_div((uint32_t)(b.quad ? 4 * per_layer : per_layer)); b.div_tiles_x = wf_make_div((uint32_t)p_all.tiles_x);
     }
     // fork: the parts' streams start behind everything the caller's stream holds so far

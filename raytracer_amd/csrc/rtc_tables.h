@@ -94,6 +94,7 @@ template <typename R> struct SceneT {
     int n_media;             // media among prims (stochastic hits)
     int leaf_kinds;          // BVH leaves: bit 0 rects, bit 1 spheres, bit 2 moving spheres, bit 3 boxes (RTC_KIND_*, rt_core.hpp)
     int tex_kinds;           // texture types in the scene: bit RTC_TEX_*
+    int n_perlin;            // noise slots behind perlin_vec / perlin_perm
     int media_kind;          // BVH leaves: 0 no media, 1 sphere-bounded media only (BLeaf carries them), 2 general boundaries
     int n_bleaves;           // records of bleaves (one per leaf slot)
     int n_general;           // leaf slots whose shading record is marked RTC_SF_GENERAL (0: the wavefront never launches k_wf_shade)

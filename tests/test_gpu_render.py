@@ -1361,3 +1361,37 @@ def test_extend_from_lds_tables_equals_the_plain_extend(gpu, monkeypatch):
         assert sc.extend_info()["lds_tables"] == 0
     finally:
         sc.close()
+
+
+@pytest.mark.parametrize("n_textures", [1, 2, 3])
+def test_noise_tables_in_lds_change_nothing(gpu, n_textures, monkeypatch):
+    """k_wf_shade keeps the permutation and vector tables of up to two noise textures in LDS (perlin.c:33-50,108-148 read through
+    ds_read instead of global loads); a scene with three reads them from memory as before.  Same values, same arithmetic: the
+    accumulators are bit-identical with the tables in LDS and with RTC_WF_NOISE_LDS=0, for one, two and three noise textures of different
+    scale, and the wavefront image agrees with the megakernel's (which never had the tables in LDS) as tightly as on the reference's scenes."""
+    L = gpu.lib()
+    v3 = gpu.api.v3
+    world = L.hittable_list_new(128)
+    mats = [L.material_lambertian_new(L.texture_noise_init_scaled(2.0 + 1.5 * k)) for k in range(n_textures)]
+    L.hittable_sphere_new(world, v3((0, -1000, 0)), 1000.0, mats[0])
+    for i in range(80):
+        L.hittable_sphere_new(world, v3((-9 + 2 * (i % 10), 0.8, -7 + 2 * (i // 10))), 0.8, mats[i % n_textures])
+    sc = gpu.Scene(world, None, (0.7, 0.8, 1.0))
+    cam = gpu.Camera((13, 4, 3), (0, 0, 0), (0, 1, 0), 40.0, 160 / 96, 0.0, 10.0)
+    try:
+        assert sc.bvh_info()["nodes"] > 0
+        W, H, spp = 160, 96, 128
+        a, sa = sc.render(cam, gpu.Settings(W, H, spp, 8, 1, seed=5, kernel=3))
+        monkeypatch.setenv("RTC_WF_NOISE_LDS", "0")
+        b, sb = sc.render(cam, gpu.Settings(W, H, spp, 8, 1, seed=5, kernel=3))
+        monkeypatch.delenv("RTC_WF_NOISE_LDS")
+        m, sm = sc.render(cam, gpu.Settings(W, H, spp, 8, 1, seed=5, kernel=1))
+    finally:
+        sc.close()
+    assert sa["kernel_used"] == 3 and sb["kernel_used"] == 3 and sm["kernel_used"] == 1
+    assert np.array_equal(a, b) and sa["rays"] == sb["rays"]
+    ia, im = clip01(mean_image(a)), clip01(mean_image(m))
+    blk = np.sqrt(((block_means(ia) - block_means(im)) ** 2).mean(axis=(0, 1)))
+    print(f"{n_textures} noise textures: blk4 vs megakernel {blk.round(5)}, rays {sa['rays']} vs {sm['rays']}")
+    assert ia.std() > 0.05                                       # (the marble is there)
+    assert blk.max() <= 0.001 and abs(sa["rays"] - sm["rays"]) <= 0.005 * sm["rays"]

@@ -428,13 +428,20 @@ __global__ void __launch_bounds__(kWfLdsBlock) __attribute__((amdgpu_waves_per_e
 // wait (and once more at the end): dense waves whatever the density of the list.  The queued entries are counting-sorted in LDS
 // by (material type, texture type) of what they hit, so a wave runs one arm of the material switch instead of all of them.
 // Only slot ids move; no global atomics; the order of the work is a function of the list alone.
+// 256 threads per workgroup, four workgroups per CU, and NO register ceiling below the hardware's (waves_per_eu 3: 142 / 12x VGPRs, no
+// spills).  Until the last session of round 3 this was 1024 threads at 5 waves per SIMD (96 VGPRs, spills in both variants) -- tuned when the
+// kernel shaded every hit.  It now shades the few per cent extend parks, it is latency-bound (dependent table loads), and it runs beside
+// the other parts' extend launches: what counts is how long its waves stay resident, not how many fit.  One GPU run, 1024 x 5 / 256 x 3:
+// final 74.1 / 72.9 ms, final + earth 134.0 / 129.0, Book-2 random (checker ground: a third of the hits parked) 28.7 / 26.5; 256 x 2, 256 x 4,
+// 128 x 3, 512 x 3 within 1 % of 256 x 3 (tools/ab_configs.sh).
 #ifndef RT_WF_SHADE_BLOCK
-#define RT_WF_SHADE_BLOCK 1024
+#define RT_WF_SHADE_BLOCK(noise) 256
 #endif
-constexpr int kWfShadeBlock = RT_WF_SHADE_BLOCK;
 #ifndef RT_WF_SHADE_WAVES
-#define RT_WF_SHADE_WAVES 5      // resident waves per SIMD (96 VGPRs: no spills in either variant; 6 waves measured the same within 0.5 %)
+#define RT_WF_SHADE_WAVES(noise) 3
 #endif
+constexpr int wf_shade_block(bool noise) { return RT_WF_SHADE_BLOCK(noise); }
+constexpr int wf_shade_waves(bool noise) { return RT_WF_SHADE_WAVES(noise); }
 // The turbulence of a noise texture is 7 octaves x 8 lattice corners x (3 permutation + 3 vector words): 210 dependent-pair table loads per hit
 // from 6 KB of tables.  The workgroup keeps the tables of up to kWfShadeNoiseSlots noise textures in LDS and hands the shading code
 // generic pointers to them (a scene with more noise textures reads them from memory as before).
@@ -443,8 +450,8 @@ constexpr int kWfShadeNoiseSlots = 2;
 // before this trip's are looked at): with one key per thread and two barriers per 1024 entries the scan of a sparse list -- 2-3 % parked --
 // was most of this kernel's time.  The queue is a ring of 8192 entries (list position + key) in LDS.
 template <bool NOISE>
-__global__ void __launch_bounds__(kWfShadeBlock) __attribute__((amdgpu_waves_per_eu(RT_WF_SHADE_WAVES))) k_wf_shade(WfArgs a) {
-    constexpr unsigned N = kWfShadeBlock, KPT = 4, QCAP = 8 * N;
+__global__ void __launch_bounds__(wf_shade_block(NOISE)) __attribute__((amdgpu_waves_per_eu(wf_shade_waves(NOISE)))) k_wf_shade(WfArgs a) {
+    constexpr unsigned N = wf_shade_block(NOISE), KPT = 4, QCAP = 8 * N;
     const WfBuffers &B = a.B;
     if (B.counters[WF_LIVE] == 0) return;
     const unsigned n_list = B.counters[WF_NLIST]; const int cur = (int)B.counters[WF_CUR];
@@ -642,10 +649,12 @@ hipError_t launch_wf_bounce(const SceneT<float> &sc, const CameraT<float> &cam, 
     else if (sc.media_kind == 1) hipLaunchKernelGGL((k_wf_extend<1, RTC_KIND_ALL>), dim3(blocks), dim3(kWfExtendBlock), lds, stream, args);
     else hipLaunchKernelGGL((k_wf_extend<2, RTC_KIND_ALL>), dim3(blocks), dim3(kWfExtendBlock), lds, stream, args);
     if (sc.n_general == 0) return hipGetLastError();               // every hit was shaded in extend's tail
-    static const unsigned shade_wgs = [] { const char *e = std::getenv("RTC_WF_SHADE_WGS"); const int v = e ? std::atoi(e) : 0; return v > 0 ? (unsigned)v : n_cus * (1024u / kWfShadeBlock); }();
-    const dim3 sgrid(std::min((n_max + kWfShadeBlock - 1) / kWfShadeBlock, shade_wgs));   // persistent: 1024 threads per CU
-    if (sc.tex_kinds & (1 << RTC_TEX_NOISE)) hipLaunchKernelGGL(k_wf_shade<true>, sgrid, dim3(kWfShadeBlock), 0, stream, args);
-    else hipLaunchKernelGGL(k_wf_shade<false>, sgrid, dim3(kWfShadeBlock), 0, stream, args);
+    static const unsigned shade_wgs = [] { const char *e = std::getenv("RTC_WF_SHADE_WGS"); const int v = e ? std::atoi(e) : 0; return (unsigned)(v > 0 ? v : 0); }();
+    const bool noise = (sc.tex_kinds & (1 << RTC_TEX_NOISE)) != 0;
+    const unsigned sblock = (unsigned)wf_shade_block(noise);
+    const dim3 sgrid(std::min((n_max + sblock - 1) / sblock, shade_wgs ? shade_wgs : n_cus * (1024u / sblock)));   // persistent: 1024 threads per CU
+    if (noise) hipLaunchKernelGGL(k_wf_shade<true>, sgrid, dim3(sblock), 0, stream, args);
+    else hipLaunchKernelGGL(k_wf_shade<false>, sgrid, dim3(sblock), 0, stream, args);
     return hipGetLastError();
 }
 // the camera rays of the first b.phit_k samples of every slot (b.phit); behind launch_wf_init on the part's stream, ahead of its first bounce

@@ -10,6 +10,7 @@ the kernel that ran, and the BVH shape where there is one.
   final_1024         config 3: 02 final scene, 1024x1024, 256 spp, depth 8
   final_earth_1080p  config 3 with the earth-map globe, 1920x1080, 256 spp
   book1_1080p        config 1 on the GPU: Book-1 spheres, 1920x1080, 8 spp (the reference's setting) and 64 spp
+  book2_1080p        not a BASELINE configuration: the Book-2 random scene (checker ground: every ground hit goes through k_wf_shade), 1920x1080, 64 spp
   million_1080p      config 5: 1,000,004 spheres, 1920x1080, 64 spp, depth 8
 """
 import argparse
@@ -30,6 +31,7 @@ CONFIGS = {  # name: (scene, arg, aspect, W, H, spp)
     "final_earth_1080p": ("final_earth", 0, 16 / 9, 1920, 1080, 256),
     "book1_1080p_8spp": ("book1", 0, None, 1920, 1080, 8),
     "book1_1080p": ("book1", 0, None, 1920, 1080, 64),
+    "book2_1080p": ("book2_random", 0, None, 1920, 1080, 64),
     "million_1080p": ("million", 1000, None, 1920, 1080, 64),
 }
 

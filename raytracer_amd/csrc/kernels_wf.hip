@@ -298,8 +298,11 @@ __global__ void __launch_bounds__(kWfExtendBlock) __attribute__((amdgpu_waves_pe
 // schedule mix rays of every depth (final scene: 14 G rays/s here against 6.6 G for the rays of the lists).  Same ray (primary_ray),
 // same traversal, same medium draws as extend would make for it at depth 0 -- the images are bit-identical to tracing them from the list.
 // WAVE = true: one traversal for the whole wave (rt_core.hpp bvh_closest_hit_wave: the node in SGPRs, one scalar load per node or leaf record).
+#ifndef RT_WF_PRIMARY_WAVES
+#define RT_WF_PRIMARY_WAVES(media, kinds) wf_extend_waves(media, kinds)
+#endif
 template <int MEDIA, int KINDS, bool WAVE>
-__global__ void __launch_bounds__(kWfExtendBlock) __attribute__((amdgpu_waves_per_eu(wf_extend_waves(MEDIA, KINDS)))) k_wf_primary(WfArgs a) {
+__global__ void __launch_bounds__(kWfExtendBlock) __attribute__((amdgpu_waves_per_eu(RT_WF_PRIMARY_WAVES(MEDIA, KINDS)))) k_wf_primary(WfArgs a) {
     const SceneT<float> &sc = a.sc; const RenderParams &P = a.P; const WfBuffers &B = a.B;
     extern __shared__ int lds_stack[];                               // sc.bvh_stack entries per lane
     const int slot = blockIdx.x * blockDim.x + threadIdx.x, k = (int)blockIdx.y;

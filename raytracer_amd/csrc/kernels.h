@@ -50,7 +50,7 @@ inline WfDiv wf_make_div(uint32_t d) {
     WfDiv r; r.shift = 30 + s; r.mul = (uint32_t)((((unsigned long long)1 << r.shift) + d - 1) / d);
     return r;
 }
-enum { WF_LIVE = 0, WF_CURSOR = 1, WF_NLIST = 2, WF_CUR = 3 };
+enum { WF_LIVE = 0, WF_CURSOR = 1, WF_NLIST = 2, WF_CUR = 3, WF_LIVE0 = 4 };   // LIVE: as of the last compaction point (never too low); LIVE0: at the start of the render
 struct WfBuffers {
     float4 *ro, *rd, *tm, *sum;       // origin | time, direction | throughput.x, throughput.yz | sample + (depth << 24) | leaf slot
                                       // the ray starts on (int bits), radiance sum of the slot; the pixel follows from the slot
@@ -60,7 +60,7 @@ struct WfBuffers {
     int *active[2];                   // slot lists (ping-pong across compactions); -1 = hole
     unsigned *counters;               // 16 words, device-side control of the render (WF_*): live slots, compaction cursor, length and
                                       // buffer index of the current slot list -- the host enqueues a fixed schedule and never reads them
-    unsigned long long *stats;        // wf_stats_bytes(): 16 striped partial counters (rays, extend waves) behind one unused line; scene-wide like the pool
+    unsigned long long *stats;        // wf_stats_bytes(): striped partial counters (rays, extend waves, dead slots) behind one unused line; scene-wide like the pool
     unsigned long long *stats_out;    // [0] rays, [1] extend waves of the calling stream: k_wf_finish folds the stripes into them
     int n_slots, slots_per_layer, layers;
     int quad;                         // slot <-> (pixel, layer) mapping of kernels_wf.hip slot_pixel

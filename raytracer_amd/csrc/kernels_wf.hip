@@ -27,10 +27,22 @@
 namespace {
 
 // (slot sums: no-return atomics instead of the read-modify-write measured 1-3 % slower, round 3)
-// live-slot counter: one atomic per wave that has something to report (a slot dies once per render)
-__device__ __forceinline__ void wave_count_sub(unsigned *__restrict__ counter, bool pred) {
+// Live slots = the count k_wf_init wrote (WF_LIVE0) minus the deaths reported since, and the deaths are a STRIPED statistic like the ray counts
+// (B.stats, kWfStripes cache lines; one fire-and-forget atomic per wave that has something to report): a device-scope atomic costs ~10 ns
+// on its address whether or not anything waits for its result -- k_wf_init spent 200 of its 350 us on 21,600 of them -- and in the second
+// half of a render nearly every wave of an extend launch reports a death.  Who needs the count sums the stripes: the compaction kernels
+// (every wave for itself, one stripe per lane), and k_wf_flip folds it into counters[WF_LIVE] for the early exits of extend and shade,
+// which may lag behind (a stale count is only ever too high).
+constexpr int kWfStripes = 64;   // cache lines each statistic is striped over
+__device__ __forceinline__ void wave_count_deaths(const WfBuffers &B, unsigned stripe, bool pred) {
     const unsigned long long m = __builtin_amdgcn_ballot_w64(pred);
-    if (m != 0 && (threadIdx.x & 63) == __builtin_ctzll(m)) atomicSub(counter, (unsigned)__builtin_popcountll(m));
+    if (m != 0 && (threadIdx.x & 63) == __builtin_ctzll(m)) atomicAdd(B.stats + 8 * (1 + 2 * kWfStripes + (stripe & (kWfStripes - 1))), (unsigned long long)__builtin_popcountll(m));
+}
+__device__ __forceinline__ unsigned wf_live_now(const WfBuffers &B) {          // called by whole waves
+    unsigned d = (unsigned)B.stats[8 * (1 + 2 * kWfStripes + (threadIdx.x & 63))];
+#pragma unroll
+    for (int off = 32; off; off >>= 1) d += __shfl_xor(d, off);
+    return B.counters[WF_LIVE0] - d;
 }
 
 // Slot <-> (pixel, layer).  A wave is 64 consecutive slots.  quad = 0: one 8x8-pixel tile, one layer.  quad = 1 (layers a
@@ -207,9 +219,12 @@ __global__ void __launch_bounds__(256) k_wf_init(CameraT<float> cam, RenderParam
         }
         B.active[0][slot] = live ? slot : -1;
     }
-    const int n = __syncthreads_count(live);                         // one atomic per block
-    if (threadIdx.x == 0 && n) atomicAdd(B.counters + WF_LIVE, (unsigned)n);
-    if (slot == 0) { B.counters[WF_NLIST] = (unsigned)B.n_slots; B.counters[WF_CUR] = 0u; B.counters[WF_CURSOR] = 0u; }
+    // the number of live slots needs no counting: every pixel of the image has one slot per layer, and a part has at least as many samples
+    // as layers (render_wavefront) -- one atomic per block on one address, 21,600 of them for 5.5 M slots, was what this kernel waited for
+    if (slot == 0) {
+        B.counters[WF_LIVE] = B.counters[WF_LIVE0] = P.max_depth > 0 ? (unsigned)P.width * (unsigned)P.height * (unsigned)min(B.layers, P.s_end - P.s_begin) : 0u;
+        B.counters[WF_NLIST] = (unsigned)B.n_slots; B.counters[WF_CUR] = 0u; B.counters[WF_CURSOR] = 0u;
+    }
 }
 
 // counters: [0] live slots, [1] cursor of the compaction; stats (64-bit): [0] rays, [1] extend waves with a live lane
@@ -227,7 +242,6 @@ template <int MEDIA> struct WfMedium;
 template <> struct WfMedium<0> { using type = NoMedium32; };
 template <> struct WfMedium<1> { using type = MediumSphereOnly; };
 template <> struct WfMedium<2> { using type = MediumSampler; };
-constexpr int kWfStripes = 64;   // cache lines each statistic is striped over
 // (Round 3, measured and dropped: an XCD-aware block -> chunk mapping -- block b on chunk (b % 8) * (n / 8) + b / 8, so that each XCD's L2 sees one
 // contiguous eighth of the slot list, a band of the image -- was 1-4 % SLOWER on final, book1 and the 1M spheres: the bands differ in cost
 // (sky against ground) and the XCDs then finish at different times; the round-robin deal balances them.)
@@ -281,7 +295,7 @@ __global__ void __launch_bounds__(kWfExtendBlock) __attribute__((amdgpu_waves_pe
         if (died) t.B.active[cur][i] = -1;                           // stays in the list as a hole until the next compaction
     }
     if (sc.n_general && i < n_list) B.key[i] = key;                  // by LIST position: k_wf_shade scans them with coalesced reads
-    wave_count_sub(B.counters + 0, died);
+    wave_count_deaths(B, blockIdx.x, died);
     // statistics: two fire-and-forget atomics per block, striped over kWfStripes cache lines each (a known hit was counted by k_wf_primary)
     const unsigned long long mask = __builtin_amdgcn_ballot_w64(live && !known);
     const int rays = __syncthreads_count(live && !known);
@@ -413,7 +427,7 @@ __global__ void __launch_bounds__(kWfLdsBlock) __attribute__((amdgpu_waves_per_e
             if (died) t.B.active[cur][i] = -1;
         }
         if (sc.n_general && i < n_list) B.key[i] = key;
-        wave_count_sub(B.counters + 0, died);
+        wave_count_deaths(B, blockIdx.x * (kWfLdsBlock / 64) + wave, died);
         const unsigned long long mask = __builtin_amdgcn_ballot_w64(live && !known);
         n_rays += (unsigned long long)__builtin_popcountll(mask); n_waves += mask != 0;
     }
@@ -530,7 +544,7 @@ __global__ void __launch_bounds__(wf_shade_block(NOISE)) __attribute__((amdgpu_w
                 else died = wf_shade_entry<NOISE, true>(t.sc, t.cam, t.P, t.B, slot, px, py, o, d, tm, hh.x, __float_as_int(hh.y), none, no_key);
                 if (died) t.B.active[cur][i] = -1;                   // stays in the list as a hole until the next compaction
             }
-            wave_count_sub(B.counters + 0, died);
+            wave_count_deaths(B, blockIdx.x * (N / 64) + wave, died);
             __syncthreads();                                         // sorted_index is free again
         }
         if (flush) break;
@@ -542,8 +556,8 @@ __global__ void __launch_bounds__(wf_shade_block(NOISE)) __attribute__((amdgpu_w
 // bounce schedule; whether the list is worth squeezing -- 1 / B.compact_div of it holes -- is decided HERE, from the device's own counters,
 // so the host never waits for a count: every block takes the same decision, and k_wf_flip, the next kernel in the stream, takes it
 // once more and makes the new list current.
-__device__ __forceinline__ bool wf_worth_compacting(const WfBuffers &B) {
-    const unsigned live = B.counters[WF_LIVE], n_list = B.counters[WF_NLIST];
+__device__ __forceinline__ bool wf_worth_compacting(const WfBuffers &B, unsigned live) {
+    const unsigned n_list = B.counters[WF_NLIST];
     return live != 0 && live < n_list - n_list / (unsigned)B.compact_div;
 }
 // A workgroup squeezes kCompactK chunks of kCompactBlock consecutive entries (held in registers) and claims its output range with ONE atomic: a
@@ -562,7 +576,7 @@ constexpr int kCompactK = RT_WF_COMPACT_K, kCompactBlock = RT_WF_COMPACT_BLOCK, 
 __global__ void __launch_bounds__(kCompactBlock) k_wf_compact(WfBuffers B) {
     __shared__ unsigned counts[kCompactK * kCompactWaves], offs[kCompactK * kCompactWaves];   // live entries per (chunk, wave), and their exclusive prefix sums
     __shared__ unsigned block_base;
-    if (!wf_worth_compacting(B)) return;
+    if (!wf_worth_compacting(B, wf_live_now(B))) return;
     const unsigned n_list = B.counters[WF_NLIST]; const int cur = (int)B.counters[WF_CUR];
     const unsigned first = blockIdx.x * (unsigned)(kCompactK * kCompactBlock);
     if (first >= n_list) return;
@@ -585,9 +599,12 @@ __global__ void __launch_bounds__(kCompactBlock) k_wf_compact(WfBuffers B) {
     for (int k = 0; k < kCompactK; ++k)
         if (slot[k] >= 0) B.active[cur ^ 1][block_base + offs[k * kCompactWaves + wave] + pos[k]] = slot[k];
 }
-__global__ void k_wf_flip(WfBuffers B) {
-    if (wf_worth_compacting(B)) { B.counters[WF_NLIST] = B.counters[WF_CURSOR]; B.counters[WF_CUR] ^= 1u; }
+__global__ void __launch_bounds__(64) k_wf_flip(WfBuffers B) {      // one wave
+    const unsigned live = wf_live_now(B);
+    if (threadIdx.x != 0) return;
+    if (wf_worth_compacting(B, live)) { B.counters[WF_NLIST] = B.counters[WF_CURSOR]; B.counters[WF_CUR] ^= 1u; }
     B.counters[WF_CURSOR] = 0;
+    B.counters[WF_LIVE] = live;                                      // what the early exits of extend and shade read
 }
 
 __global__ void __launch_bounds__(256) k_wf_finish(RenderParams P, WfBuffers B, float4 *__restrict__ accum, const unsigned long long *__restrict__ stats,
@@ -612,7 +629,7 @@ __global__ void __launch_bounds__(256) k_wf_finish(RenderParams P, WfBuffers B, 
 }  // namespace
 
 size_t wf_bytes_per_slot() { return 4 * sizeof(float4) + sizeof(float2) + 2 * sizeof(int) + 1; }
-size_t wf_stats_bytes() { return (1 + 2 * kWfStripes) * 8 * sizeof(unsigned long long); }   // cache lines of 64 bytes
+size_t wf_stats_bytes() { return (1 + 3 * kWfStripes) * 8 * sizeof(unsigned long long); }   // cache lines of 64 bytes
 
 // Does the extend stage of this scene run from LDS tables (k_wf_extend_lds)?  No media, every node index and leaf reference in 16
 // bits, and tables + 16-bit stacks of a workgroup's 768 lanes within half a CU's LDS.  RTC_WF_LDS_TABLES=0 keeps the plain kernel (A/B, tests).
@@ -627,7 +644,7 @@ bool wf_lds_tables(const SceneT<float> &sc, size_t *lds_bytes) {
 
 hipError_t launch_wf_init(const CameraT<float> &cam, const RenderParams &p, const WfBuffers &b, hipStream_t stream) {
     hipError_t e = hipMemsetAsync(b.counters, 0, 16 * sizeof(unsigned), stream);
-    if (e == hipSuccess) e = hipMemsetAsync(b.stats + 8, 0, 2 * kWfStripes * 8 * sizeof(unsigned long long), stream);
+    if (e == hipSuccess) e = hipMemsetAsync(b.stats + 8, 0, 3 * kWfStripes * 8 * sizeof(unsigned long long), stream);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_wf_init, dim3((unsigned)((b.n_slots + 255) / 256)), dim3(256), 0, stream, cam, p, b);
     return hipGetLastError();
@@ -679,7 +696,7 @@ hipError_t launch_wf_primary(const SceneT<float> &sc, const CameraT<float> &cam,
 }
 hipError_t launch_wf_compact(const WfBuffers &b, hipStream_t stream) {
     hipLaunchKernelGGL(k_wf_compact, dim3(((unsigned)b.n_slots + kCompactK * kCompactBlock - 1) / (kCompactK * kCompactBlock)), dim3(kCompactBlock), 0, stream, b);
-    hipLaunchKernelGGL(k_wf_flip, dim3(1), dim3(1), 0, stream, b);
+    hipLaunchKernelGGL(k_wf_flip, dim3(1), dim3(64), 0, stream, b);
     return hipGetLastError();
 }
 hipError_t launch_wf_finish(const RenderParams &p, const WfBuffers &b, float4 *accum, hipStream_t stream) {

@@ -595,15 +595,16 @@ static int render_wavefront(rtc_scene *s, const CameraT<float> &camf, const Rend
     const int spp_all = p_all.s_end - p_all.s_begin;
     if (spp_all <= 0) return RTC_OK;
     const long long per_layer = (long long)p_all.n_tiles * 64;
-    // parts of at least ~5 M path slots each: smaller ones lose more to their launches than the overlap gains (final 512^2 x 256 spp, 8.4 M slots:
-    // one part 33.9 ms, three 37.4; 1024^2, 32 M slots: 116 against 94)
     int sps = 8;                                                     // samples per slot aimed at
     if (const char *e = std::getenv("RTC_WF_SPS")) { const int v = std::atoi(e); if (v >= 1) sps = v; }   // A/B knob
     const long long slots_wanted = std::min<long long>((long long)((spp_all + sps - 1) / sps) * per_layer, 32ll << 20);
-    int n_parts = (int)std::max<long long>(1, std::min<long long>(3, slots_wanted / (5ll << 20)));
-    // trees traversed from LDS (k_wf_extend_lds: persistent workgroups, two per CU) overlap better still: up to four parts of about 4 M slots (book1 1080p x 64 spp,
-    // one GPU run: 1 / 2 / 3 / 4 parts = 31.6 / 23.8 / 21.7 / 19.9 ms; the final scene and the 1M spheres are best at three: 107 / 91.6 / 88.4 / 89.7, 44.6 / 38.5 / 37.0 / 37.1)
-    if (wf_lds_tables(s->f32.view, nullptr)) n_parts = (int)std::max<long long>(1, std::min<long long>(4, (slots_wanted + (2ll << 20)) / (4ll << 20)));
+    // Re-measured at the end of round 3, after the live-slot counter stopped serialising every part on one address (which is what more
+    // parts had mostly bought: each has counters of its own).  One GPU run, 1 / 2 / 3 / 4 parts: final 75.5 / 69.3 / 68.8 / 67.9 ms, final + earth
+    // 138.5 / 125.5 / 124.6 / 123.0, 1M spheres 32.7 / 30.4 / 30.5 / 30.2; trees traversed from LDS (k_wf_extend_lds: persistent workgroups that
+    // fill the GPU by themselves): book1 15.0 / 13.8 / 14.2 / 14.7, Book-2 random 26.1 / 24.3 / 24.5 / 24.3.  So: up to four parts of >= 4 M slots,
+    // two for the LDS kernels.
+    int n_parts = (int)std::max<long long>(1, std::min<long long>(4, slots_wanted / (4ll << 20)));
+    if (wf_lds_tables(s->f32.view, nullptr)) n_parts = std::min(n_parts, 2);
     if (const char *e = std::getenv("RTC_WF_PARTS")) { const int v = std::atoi(e); if (v >= 1 && v <= RTC_WF_MAX_PARTS) n_parts = v; }   // A/B knob
     if (n_parts > spp_all) n_parts = spp_all;
     // Slots per pixel ("layers").  A slot walks through its samples one after the other, so a render lasts as many bounces

@@ -66,8 +66,8 @@ PEAK_L2_GBS = 34500.0             # MI355X_MICROARCH.md: 8 x 4 MiB L2, ~34.5 TB/
 #               the instrumented oracle run of tests/flop_model.py on the same scene (hit records, media, textures, materials,
 #               camera): final 128.1, final_earth 119.4, book1 32.8
 # Which roof: final / final_earth / book1 keep their trees (<= 285 KB) in L2 and are bound by VALU issue under divergence
-# (profiles/r03d/final: extend active-lane 0.19, wait 0.59) -> "valu"; the 1M-sphere tree (105 MB) is served by L2 + Infinity Cache
-# (profiles/r03d/million: TCC hit rate 0.61) -> "l2", with the L2 requests counted by rocprofv3 beside the algorithmic bytes.
+# (profiles/r03f/final: extend active-lane 0.24) -> "valu"; the 1M-sphere tree (105 MB) is served by L2 + Infinity Cache
+# (profiles/r03f/million) -> "l2", with the L2 requests counted by rocprofv3 beside the algorithmic bytes.
 SCENE_MODEL = {
     # (final / final_earth: trees with one record per leaf and the global fog hung off the root since the end of round 3 -- the round-2 probe counts
     # 10.4 + 3.3 and 10.0 + 2.7 scaled by the host traversal model's ratio between the old and the new tree, tools/exp/sim_traversal.py: 15.4 -> 12.2 trips
@@ -108,12 +108,12 @@ def scene_roofline(scene, rays_per_launch, k_ms, rays_per_sample=None):
 
 
 def measured_l2_requests(scene):
-    """TCC_HIT + TCC_MISS of k_wf_extend per launch from the committed rocprofv3 pass of this scene (profiles/r03d), or None."""
+    """TCC_HIT + TCC_MISS of k_wf_extend per launch from the committed rocprofv3 pass of this scene (profiles/r03f), or None."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r03d", scene, "summary.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r03f", scene, "summary.json")) as f:
             s = json.load(f)
         p = s["pmc_per_launch"]
-        return {"profile": "r03d/" + scene, "kernel": s.get("kernel"), "tcc_hit_per_launch": p["TCC_HIT_sum"], "tcc_miss_per_launch": p["TCC_MISS_sum"],
+        return {"profile": "r03f/" + scene, "kernel": s.get("kernel"), "tcc_hit_per_launch": p["TCC_HIT_sum"], "tcc_miss_per_launch": p["TCC_MISS_sum"],
                 "hit_rate": p["TCC_HIT_sum"] / (p["TCC_HIT_sum"] + p["TCC_MISS_sum"]), "kernel_ms": s.get("avg_ms")}
     except (OSError, KeyError, ValueError, ZeroDivisionError):
         return None

@@ -595,7 +595,11 @@ static int render_wavefront(rtc_scene *s, const CameraT<float> &camf, const Rend
     const int spp_all = p_all.s_end - p_all.s_begin;
     if (spp_all <= 0) return RTC_OK;
     const long long per_layer = (long long)p_all.n_tiles * 64;
-    int sps = 8;                                                     // samples per slot aimed at
+    // samples per slot aimed at: ONE -- a slot per sample until the cap of 32 M slots is reached (1080p from 16 spp, 1024^2 from 32 spp), because a slot walks
+    // through its samples one after the other and the render lasts as many rounds as the unluckiest slot needs.  It was 8 until the end of round 3,
+    // which only mattered below the cap: book1 1080p x 8 spp (config 1) 3.33 ms at 8 samples per slot, 2.69 / 2.66 / 2.36 at 4 / 2 / 1; at 64 spp and
+    // for the 1M spheres all four are within 1 %.
+    int sps = 1;
     if (const char *e = std::getenv("RTC_WF_SPS")) { const int v = std::atoi(e); if (v >= 1) sps = v; }   // A/B knob
     const long long slots_wanted = std::min<long long>((long long)((spp_all + sps - 1) / sps) * per_layer, 32ll << 20);
     // Re-measured at the end of round 3, after the live-slot counter stopped serialising every part on one address (which is what more

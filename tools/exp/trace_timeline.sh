@@ -18,7 +18,7 @@ rows.sort(key=lambda r: r[1])
 # the last render = from the last k_wf_init group backwards: take the final third of the trace's wf kernels
 wf = [r for r in rows if "k_wf_" in r[0]]
 fin = [i for i, r in enumerate(wf) if "k_wf_finish" in r[0]]
-n_parts = 3
+n_parts = int(__import__("os").environ.get("TL_PARTS", "3"))
 start_i = fin[-n_parts - 1] + 1 if len(fin) > n_parts else 0
 last = wf[start_i:]
 t0, t1 = min(r[1] for r in last), max(r[2] for r in last)

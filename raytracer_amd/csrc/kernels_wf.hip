@@ -34,12 +34,20 @@ namespace {
 // (every wave for itself, one stripe per lane), and k_wf_flip folds it into counters[WF_LIVE] for the early exits of extend and shade,
 // which may lag behind (a stale count is only ever too high).
 constexpr int kWfStripes = 64;   // cache lines each statistic is striped over
-__device__ __forceinline__ void wave_count_deaths(const WfBuffers &B, unsigned stripe, bool pred) {
-    const unsigned long long m = __builtin_amdgcn_ballot_w64(pred);
-    if (m != 0 && (threadIdx.x & 63) == __builtin_ctzll(m)) atomicAdd(B.stats + 8 * (1 + 2 * kWfStripes + (stripe & (kWfStripes - 1))), (unsigned long long)__builtin_popcountll(m));
+// What a wave of the bounce schedule reports -- rays traced, 1 if it held a live lane, slots that died -- goes out as ONE atomic on a packed word of
+// its stripe: rays (24 bits) | waves (20) | dead slots (20).  k_wf_flip, alone on its part's stream at every compaction point, unpacks the words into the
+// wide per-stripe sums and clears them, so a field holds at most the counts of the rounds between two compaction points (<= 16: render_wavefront) of
+// 1/64 of <= 32 M slots; k_wf_finish adds what the last rounds left.  (Three atomics per wave instead of one: final 67.7 -> 65.8 ms without any.)
+constexpr int kWfPackWaves = 24, kWfPackDeaths = 44;
+__device__ __forceinline__ unsigned long long *wf_packed(const WfBuffers &B, unsigned stripe) { return B.stats + 8 * (1 + 2 * kWfStripes + (stripe & (kWfStripes - 1))); }   // [0] packed, [1] dead slots folded so far
+__device__ __forceinline__ void wave_report(const WfBuffers &B, unsigned stripe, unsigned long long rays_mask, unsigned long long died_mask) {   // one lane calls
+    const unsigned long long v = (unsigned long long)__builtin_popcountll(rays_mask) | ((unsigned long long)(rays_mask != 0) << kWfPackWaves)
+                               | ((unsigned long long)__builtin_popcountll(died_mask) << kWfPackDeaths);
+    if (v) atomicAdd(wf_packed(B, stripe), v);
 }
 __device__ __forceinline__ unsigned wf_live_now(const WfBuffers &B) {          // called by whole waves
-    unsigned d = (unsigned)B.stats[8 * (1 + 2 * kWfStripes + (threadIdx.x & 63))];
+    const unsigned long long *st = wf_packed(B, threadIdx.x & 63);
+    unsigned d = (unsigned)(st[0] >> kWfPackDeaths) + (unsigned)st[1];
 #pragma unroll
     for (int off = 32; off; off >>= 1) d += __shfl_xor(d, off);
     return B.counters[WF_LIVE0] - d;
@@ -295,15 +303,9 @@ __global__ void __launch_bounds__(kWfExtendBlock) __attribute__((amdgpu_waves_pe
         if (died) t.B.active[cur][i] = -1;                           // stays in the list as a hole until the next compaction
     }
     if (sc.n_general && i < n_list) B.key[i] = key;                  // by LIST position: k_wf_shade scans them with coalesced reads
-    wave_count_deaths(B, blockIdx.x, died);
-    // statistics: two fire-and-forget atomics per block, striped over kWfStripes cache lines each (a known hit was counted by k_wf_primary)
-    const unsigned long long mask = __builtin_amdgcn_ballot_w64(live && !known);
-    const int rays = __syncthreads_count(live && !known);
-    const int waves = __syncthreads_count(mask != 0 && (threadIdx.x & 63) == 0);
-    if (threadIdx.x == 0 && rays) {
-        atomicAdd(B.stats + 8 * (1 + (blockIdx.x & (kWfStripes - 1))), (unsigned long long)rays);
-        atomicAdd(B.stats + 8 * (1 + kWfStripes + (blockIdx.x & (kWfStripes - 1))), (unsigned long long)waves);
-    }
+    // statistics and the slots that died: one fire-and-forget atomic per wave (a known hit was counted by k_wf_primary)
+    const unsigned long long rays_mask = __builtin_amdgcn_ballot_w64(live && !known), died_mask = __builtin_amdgcn_ballot_w64(died);
+    if ((threadIdx.x & 63) == 0) wave_report(B, blockIdx.x * (kWfExtendBlock / 64) + (threadIdx.x >> 6), rays_mask, died_mask);
 }
 
 // The camera rays of a render, traced ahead of its bounce schedule: entry (k, slot) = the closest hit of the slot's k-th sample, written
@@ -396,7 +398,7 @@ __global__ void __launch_bounds__(kWfLdsBlock) __attribute__((amdgpu_waves_per_e
     // persistent: a workgroup owns a contiguous slice of the list's 64-entry chunks and its 12 waves claim them one at a time from a counter
     // in LDS (a same-address atomic in HBM costs ~11 ns and serialises: one per chunk was 12 % slower than the static partition it replaced)
     // -- no barrier after the copy, so a workgroup's waves do not wait for its slowest one, and the table is copied once per workgroup
-    unsigned long long n_rays = 0, n_waves = 0;
+    unsigned long long n_rays = 0, n_waves = 0, n_died = 0;
     const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const unsigned n_chunks = (n_list + 63u) / 64u, per_wg = (n_chunks + gridDim.x - 1) / gridDim.x;
     const unsigned wg_first = blockIdx.x * per_wg, wg_end = wg_first + per_wg < n_chunks ? wg_first + per_wg : n_chunks;
@@ -427,14 +429,13 @@ __global__ void __launch_bounds__(kWfLdsBlock) __attribute__((amdgpu_waves_per_e
             if (died) t.B.active[cur][i] = -1;
         }
         if (sc.n_general && i < n_list) B.key[i] = key;
-        wave_count_deaths(B, blockIdx.x * (kWfLdsBlock / 64) + wave, died);
         const unsigned long long mask = __builtin_amdgcn_ballot_w64(live && !known);
         n_rays += (unsigned long long)__builtin_popcountll(mask); n_waves += mask != 0;
+        n_died += (unsigned long long)__builtin_popcountll(__builtin_amdgcn_ballot_w64(died));
     }
-    if (lane == 0 && n_rays) {
-        atomicAdd(B.stats + 8 * (1 + ((blockIdx.x * (kWfLdsBlock / 64) + wave) & (kWfStripes - 1))), n_rays);
-        atomicAdd(B.stats + 8 * (1 + kWfStripes + ((blockIdx.x * (kWfLdsBlock / 64) + wave) & (kWfStripes - 1))), n_waves);
-    }
+    // (a persistent wave sees n_list / (waves of the grid) entries per launch: far inside the packed fields)
+    const unsigned long long v = n_rays | (n_waves << kWfPackWaves) | (n_died << kWfPackDeaths);
+    if (lane == 0 && v) atomicAdd(wf_packed(B, blockIdx.x * (kWfLdsBlock / 64) + wave), v);
 }
 
 // The hits extend has parked for this stage (leaves marked RTC_SF_GENERAL: a perlin / image / checker texture to evaluate, a wrapper
@@ -544,7 +545,7 @@ __global__ void __launch_bounds__(wf_shade_block(NOISE)) __attribute__((amdgpu_w
                 else died = wf_shade_entry<NOISE, true>(t.sc, t.cam, t.P, t.B, slot, px, py, o, d, tm, hh.x, __float_as_int(hh.y), none, no_key);
                 if (died) t.B.active[cur][i] = -1;                   // stays in the list as a hole until the next compaction
             }
-            wave_count_deaths(B, blockIdx.x * (N / 64) + wave, died);
+            { const unsigned long long dm = __builtin_amdgcn_ballot_w64(died); if (lane == 0) wave_report(B, blockIdx.x * (N / 64) + wave, 0ull, dm); }
             __syncthreads();                                         // sorted_index is free again
         }
         if (flush) break;
@@ -601,6 +602,15 @@ __global__ void __launch_bounds__(kCompactBlock) k_wf_compact(WfBuffers B) {
 }
 __global__ void __launch_bounds__(64) k_wf_flip(WfBuffers B) {      // one wave
     const unsigned live = wf_live_now(B);
+    {   // unpack this stripe's word into the wide sums (nothing else of this part runs beside this kernel)
+        unsigned long long *const st = wf_packed(B, threadIdx.x);
+        const unsigned long long p = st[0];
+        if (p) {
+            B.stats[8 * (1 + threadIdx.x)] += p & ((1ull << kWfPackWaves) - 1);
+            B.stats[8 * (1 + kWfStripes + threadIdx.x)] += (p >> kWfPackWaves) & ((1ull << (kWfPackDeaths - kWfPackWaves)) - 1);
+            st[1] += p >> kWfPackDeaths; st[0] = 0;
+        }
+    }
     if (threadIdx.x != 0) return;
     if (wf_worth_compacting(B, live)) { B.counters[WF_NLIST] = B.counters[WF_CURSOR]; B.counters[WF_CUR] ^= 1u; }
     B.counters[WF_CURSOR] = 0;
@@ -612,7 +622,11 @@ __global__ void __launch_bounds__(256) k_wf_finish(RenderParams P, WfBuffers B, 
     const int q = blockIdx.x * blockDim.x + threadIdx.x;            // slot of layer 0
     if (q == 0) {                                                    // fold the striped statistics into the calling stream's counters
         unsigned long long rays = 0, waves = 0;
-        for (int k = 0; k < kWfStripes; ++k) { rays += stats[8 * (1 + k)]; waves += stats[8 * (1 + kWfStripes + k)]; }
+        for (int k = 0; k < kWfStripes; ++k) {
+            const unsigned long long p = stats[8 * (1 + 2 * kWfStripes + k)];   // what the rounds behind the last compaction point reported
+            rays += stats[8 * (1 + k)] + (p & ((1ull << kWfPackWaves) - 1));
+            waves += stats[8 * (1 + kWfStripes + k)] + ((p >> kWfPackWaves) & ((1ull << (kWfPackDeaths - kWfPackWaves)) - 1));
+        }
         stats_out[0] += rays; stats_out[1] += waves;
     }
     if (q >= B.slots_per_layer) return;

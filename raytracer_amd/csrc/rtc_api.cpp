@@ -708,7 +708,7 @@ static int render_wavefront(rtc_scene *s, const CameraT<float> &camf, const Rend
     // every / fraction: 8 / 4 -> 2 / 16: final 88.8 -> 83.8 ms, final + earth 154.8 -> 149.7, book1 19.5 -> 17.2, 1M spheres 36.7 -> 35.8;
     // 1 / 32: 86.7, 153.7, 17.8, 36.3; never squeezing below the threshold (2 / 10^6): 84.3, 150.3, 17.5, 36.2 -- profiles/r03e/compaction_sweep.txt.)
     long long compact_every = 2;
-    if (const char *e = std::getenv("RTC_WF_COMPACT_EVERY")) compact_every = std::max(1ll, std::atoll(e));   // A/B knob
+    if (const char *e = std::getenv("RTC_WF_COMPACT_EVERY")) compact_every = std::min(16ll, std::max(1ll, std::atoll(e)));   // A/B knob (<= 16: the packed statistics of kernels_wf.hip are unpacked at compaction points)
     for (long long it = 0; it < longest; ++it)                       // round robin, so that the parts' kernels reach the GPU interleaved
         for (int k = 0; k < n_parts; ++k) {
             if (it >= part[k].iterations) continue;

@@ -38,8 +38,8 @@ constexpr int kWfStripes = 64;   // cache lines each statistic is striped over
 // its stripe: rays (24 bits) | waves (20) | dead slots (20).  k_wf_flip, alone on its part's stream at every compaction point, unpacks the words into the
 // wide per-stripe sums and clears them, so a field holds at most the counts of the rounds between two compaction points (<= 16: render_wavefront) of
 // 1/64 of <= 32 M slots; k_wf_finish adds what the last rounds left.  (Three atomics per wave instead of one: final 67.7 -> 65.8 ms without any.)
-constexpr int kWfPackWaves = 24, kWfPackDeaths = 44;
-__device__ __forceinline__ unsigned long long *wf_packed(const WfBuffers &B, unsigned stripe) { return B.stats + 8 * (1 + 2 * kWfStripes + (stripe & (kWfStripes - 1))); }   // [0] packed, [1] dead slots folded so far
+constexpr int kWfPackWaves = 24, kWfPackDeaths = 44, kWfPackPrimaryWaves = 40;
+__device__ __forceinline__ unsigned long long *wf_packed(const WfBuffers &B, unsigned stripe) { return B.stats + 8 * (1 + 2 * kWfStripes + (stripe & (kWfStripes - 1))); }   // [0] packed, [1] dead slots folded so far, [2] k_wf_primary's rays | waves << 40
 __device__ __forceinline__ void wave_report(const WfBuffers &B, unsigned stripe, unsigned long long rays_mask, unsigned long long died_mask) {   // one lane calls
     const unsigned long long v = (unsigned long long)__builtin_popcountll(rays_mask) | ((unsigned long long)(rays_mask != 0) << kWfPackWaves)
                                | ((unsigned long long)__builtin_popcountll(died_mask) << kWfPackDeaths);
@@ -357,13 +357,11 @@ __global__ void __launch_bounds__(kWfExtendBlock) __attribute__((amdgpu_waves_pe
         const HitS h = bvh_closest_hit_wave<KINDS>(sc, r, live, 0.001f, Mth<float>::inf(), lds_stack, medium);   // ray.c:56
         if (live) B.phit[(size_t)k * (size_t)B.n_slots + (size_t)slot] = make_float2(h.t, __int_as_float(h.slot));
     }
+    // statistics: one atomic per wave on a word of its own in the stripe's line, rays (40 bits) | waves (24) -- a launch is at most 32 M slots x 32
+    // samples over 64 stripes; k_wf_finish unpacks
     const unsigned long long mask = __builtin_amdgcn_ballot_w64(live);
-    const int rays = __syncthreads_count(live);
-    const int waves = __syncthreads_count(mask != 0 && (threadIdx.x & 63) == 0);
-    if (threadIdx.x == 0 && rays) {
-        atomicAdd(B.stats + 8 * (1 + (blockIdx.x & (kWfStripes - 1))), (unsigned long long)rays);
-        atomicAdd(B.stats + 8 * (1 + kWfStripes + (blockIdx.x & (kWfStripes - 1))), (unsigned long long)waves);
-    }
+    if ((threadIdx.x & 63) == 0 && mask)
+        atomicAdd(wf_packed(B, (blockIdx.x + blockIdx.y) * (kWfExtendBlock / 64) + (threadIdx.x >> 6)) + 2, (unsigned long long)__builtin_popcountll(mask) | (1ull << kWfPackPrimaryWaves));
 }
 
 // Extend for SMALL trees (book1: 281 nodes + 486 leaf records = 49 KB): a workgroup of 768 threads copies the node and the leaf table
@@ -624,8 +622,9 @@ __global__ void __launch_bounds__(256) k_wf_finish(RenderParams P, WfBuffers B, 
         unsigned long long rays = 0, waves = 0;
         for (int k = 0; k < kWfStripes; ++k) {
             const unsigned long long p = stats[8 * (1 + 2 * kWfStripes + k)];   // what the rounds behind the last compaction point reported
-            rays += stats[8 * (1 + k)] + (p & ((1ull << kWfPackWaves) - 1));
-            waves += stats[8 * (1 + kWfStripes + k)] + ((p >> kWfPackWaves) & ((1ull << (kWfPackDeaths - kWfPackWaves)) - 1));
+            const unsigned long long q = stats[8 * (1 + 2 * kWfStripes + k) + 2];   // the camera pass
+            rays += stats[8 * (1 + k)] + (p & ((1ull << kWfPackWaves) - 1)) + (q & ((1ull << kWfPackPrimaryWaves) - 1));
+            waves += stats[8 * (1 + kWfStripes + k)] + ((p >> kWfPackWaves) & ((1ull << (kWfPackDeaths - kWfPackWaves)) - 1)) + (q >> kWfPackPrimaryWaves);
         }
         stats_out[0] += rays; stats_out[1] += waves;
     }

@@ -635,7 +635,8 @@ static int render_wavefront(rtc_scene *s, const CameraT<float> &camf, const Rend
         P.p.s_end = p_all.s_begin + (int)((long long)spp_all * (k + 1) / n_parts);
         const int spp = P.p.s_end - P.p.s_begin;
         long long layers = (spp + sps - 1) / sps;
-        if (layers * per_layer > max_slots / n_parts) layers = max_slots / n_parts / per_layer;
+        const long long part_cap = std::min(max_slots / n_parts, 32ll << 20);   // (<= 32 M slots per part whatever RTC_WF_SLOTS says: the packed statistics of kernels_wf.hip count 1/64 of a part in 20 bits)
+        if (layers * per_layer > part_cap) layers = part_cap / per_layer;
         if (layers * per_layer < (1ll << 20) / n_parts) layers = ((1ll << 20) / n_parts + per_layer - 1) / per_layer;   // small images: at least 1M slots in all
         if (layers > spp) layers = spp;
         if (layers < 1) layers = 1;

@@ -37,7 +37,9 @@ typedef struct rtc_settings {
     double mixture_light_weight; /* 0.1 (ray.c:72) */
     int kernel;                  /* 0 = auto, 1 = general megakernel (BVH, media, textures), 2 = small-scene megakernel
                                     (<= 64 rect/sphere leaves, solid textures), 3 = wavefront (BVH scenes: more than 64 leaves);
-                                    RTC_ERR_SCENE when the scene is not eligible for the kernel asked for */
+                                    RTC_ERR_SCENE when the scene is not eligible for the kernel asked for; the wavefront kernel takes
+                                    max_depth <= 255, sample_end <= 2^24 and images of at most 32 M pixels (auto falls back to 1
+                                    beyond that, asking for 3 is RTC_ERR_ARG) */
     int reserved;
 } rtc_settings;
 

@@ -759,12 +759,13 @@ int rtc_render_device(const rtc_scene *scene_c, const camera *cam, const rtc_set
     if (small && s->small.n_leaves <= 0)
         return fail(RTC_ERR_SCENE, "kernel 2 (small-scene) needs <= 64 rect/sphere leaves with solid textures and no media");
     // the wavefront path state packs (sample, depth) into 24 + 8 bits (kernels.h WfBuffers)
-    const bool wf_fits = st->max_depth <= 255 && st->sample_end <= (1 << 24);
+    // ... and its packed statistics count 1/64 of a part's slots in 20 bits: one layer of slots (64 per 8x8 tile) must not exceed 32 M (a 33-megapixel image)
+    const bool wf_fits = st->max_depth <= 255 && st->sample_end <= (1 << 24) && (long long)p.n_tiles * 64 <= (32ll << 20);
     const bool wavefront = st->kernel == 3 || (st->kernel == 0 && !small && s->f32.view.n_nodes > 0 && wf_fits);
     if (wavefront && s->f32.view.n_nodes <= 0)
         return fail(RTC_ERR_SCENE, "kernel 3 (wavefront) needs a scene that was flattened into a BVH (more than 64 leaves)");
     if (wavefront && !wf_fits)
-        return fail(RTC_ERR_ARG, "kernel 3 (wavefront) needs max_depth <= 255 and sample_end <= 2^24");
+        return fail(RTC_ERR_ARG, "kernel 3 (wavefront) needs max_depth <= 255, sample_end <= 2^24 and an image of at most 32 M pixels (in 8x8 tiles)");
     if (small) {
         if ((size_t)p.n_tiles > ss.tile_scratch_cap) {
             if (ss.tile_scratch.p) { HIP_TRY(hipStreamSynchronize(stream)); (void)hipFree(ss.tile_scratch.p); ss.tile_scratch.p = nullptr; ss.tile_scratch_cap = 0; }

@@ -1395,3 +1395,30 @@ def test_noise_tables_in_lds_change_nothing(gpu, n_textures, monkeypatch):
     print(f"{n_textures} noise textures: blk4 vs megakernel {blk.round(5)}, rays {sa['rays']} vs {sm['rays']}")
     assert ia.std() > 0.05                                       # (the marble is there)
     assert blk.max() <= 0.001 and abs(sa["rays"] - sm["rays"]) <= 0.005 * sm["rays"]
+
+
+@pytest.mark.parametrize("name,arg", [("final", 0), ("million", 60)])
+def test_wavefront_statistics_do_not_depend_on_the_schedule(gpu, name, arg, monkeypatch):
+    """Rays, waves and dead slots of a wave of the bounce schedule go out as one atomic on a packed word of a stripe (24 | 20 | 20 bits) that
+    k_wf_flip unpacks at every compaction point and k_wf_finish at the end; k_wf_init computes the number of live slots instead of counting
+    it.  Whatever the number of parts (1-4) and of rounds between compaction points (1, 7, 16 = the most the fields are sized for), the
+    ray count of a render is the same number -- the paths are functions of (pixel, sample, bounce) -- the wave count is plausible (a wave
+    holds at most 64 rays), and for one partition the accumulators do not depend on the compaction schedule at all."""
+    sc, cam, view = gpu.build_named_scene(name, arg=arg)
+    try:
+        W, H, spp = 192, 128, 96
+        out = {}
+        for parts, every in ((0, 0), (1, 1), (1, 16), (2, 7), (4, 2), (4, 16)):
+            if parts: monkeypatch.setenv("RTC_WF_PARTS", str(parts)); monkeypatch.setenv("RTC_WF_COMPACT_EVERY", str(every))
+            out[(parts, every)] = sc.render(cam, gpu.Settings(W, H, spp, view.max_depth, view.integrator, seed=11, kernel=3))
+        monkeypatch.delenv("RTC_WF_PARTS"); monkeypatch.delenv("RTC_WF_COMPACT_EVERY")
+    finally:
+        sc.close()
+    base = out[(0, 0)][1]
+    assert base["kernel_used"] == 3 and base["samples"] == W * H * spp and base["rays"] > base["samples"]
+    for key, (acc, st) in out.items():
+        assert st["rays"] == base["rays"], (key, st["rays"], base["rays"])
+        assert st["rays"] <= 64 * st["wave_iterations"] <= 64 * 40 * st["rays"], (key, st["wave_iterations"])
+        assert (acc[..., 3] == spp).all() and np.isfinite(acc).all()
+    assert np.array_equal(out[(1, 1)][0], out[(1, 16)][0]) and np.array_equal(out[(4, 2)][0], out[(4, 16)][0])
+    print(f"{name}: rays {base['rays']}, waves by schedule {[st['wave_iterations'] for _, st in out.values()]}")

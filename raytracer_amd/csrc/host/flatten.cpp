@@ -568,6 +568,9 @@ void build_leaf_shade(FlatScene &fs) {
             S.rgb[0] = S.rgb[1] = S.rgb[2] = 1.0f; S.param = (float)m.param; S.pad[0] = (float)(1.0 / m.param);
             const double r = (1.0 - m.param) / (1.0 + m.param); S.pad[1] = (float)(r * r);
         }
+        else if (m.type == RTC_MAT_LAMBERTIAN && m.tex >= 0 && fs.textures[m.tex].type == RTC_TEX_NOISE && p.type == RTC_PRIM_SPHERE) {   // albedo left to k_wf_shade (RTC_SF_TEXTURED)
+            S.rgb[0] = S.rgb[1] = S.rgb[2] = 1.0f; std::memcpy(&S.param, &m.tex, sizeof(int)); S.meta |= RTC_SF_TEXTURED;
+        }
         else if (m.tex < 0 || fs.textures[m.tex].type != RTC_TEX_SOLID) general = true;
         else for (int k = 0; k < 3; k++) S.rgb[k] = (float)fs.textures[m.tex].v[k];
         if (p.type == RTC_PRIM_RECT) {
@@ -592,7 +595,7 @@ void build_leaf_shade(FlatScene &fs) {
             S.g[0] = 1.0f;
             if (m.type != RTC_MAT_ISOTROPIC && m.type != RTC_MAT_LAMBERTIAN && m.type != RTC_MAT_METAL) general = true;   // glass / lamps read front_face against a real surface
         }
-        if (general) S.meta |= RTC_SF_GENERAL;
+        if (general) { S.meta |= RTC_SF_GENERAL; S.meta &= ~(uint32_t)RTC_SF_TEXTURED; }
         fs.leaf_shade.push_back(S);
     }
 }

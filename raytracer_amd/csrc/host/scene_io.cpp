@@ -22,7 +22,7 @@
 namespace {
 
 const char kMagic[8] = {'R', 'T', 'C', 'S', 'C', 'E', 'N', 'E'};
-const uint32_t kVersion = 3;   // 2: glass constants in SmallShade.pad, 1/area in SmallPair, 32-byte SmallSphere (round 2); 3: leaf_shade carries moving spheres, media and the regrouping key
+const uint32_t kVersion = 4;   // 4: RTC_SF_TEXTURED records in leaf_shade; 2: glass constants in SmallShade.pad, 1/area in SmallPair, 32-byte SmallSphere (round 2); 3: leaf_shade carries moving spheres, media and the regrouping key
 
 struct Header { char magic[8]; uint32_t version, n_sections; uint64_t payload_bytes; uint32_t payload_crc, pad[9]; };
 static_assert(sizeof(Header) == 64, "header layout");
@@ -147,6 +147,8 @@ bool validate_flat_scene(const FlatScene &fs, std::string &err) {
     else {
         const size_t nl = fs.leaf_prims.size();
         REQ(fs.bleaves.size() == nl && fs.leaf_shade.size() == nl, "leaf tables differ in length");
+        for (const SmallShade &sh : fs.leaf_shade)
+            if (sh.meta & RTC_SF_TEXTURED) { int t; std::memcpy(&t, &sh.param, sizeof t); REQ(t >= 0 && (size_t)t < fs.textures.size() && fs.textures[t].type == RTC_TEX_NOISE, "textured shading record without its texture"); }
         for (const int p : fs.leaf_prims) REQ(in(p, fs.prims.size()), "a leaf slot points outside the primitive table");
         std::vector<char> box_start(nl, 0);
         for (const int s : fs.box_slots) { REQ(run_in(s, 6, nl), "a box record leaves the leaf table"); box_start[(size_t)s] = 1; }

@@ -98,6 +98,10 @@ __device__ __forceinline__ bool wf_camera_hit(const RenderParams &P, const WfBuf
 //   GENERAL = false: the hit's 48-byte shading record answers everything (leaf_shade: normal or centre, resolved colour, face flags) --
 //                    the form extend runs in its own tail, for every hit that is not marked RTC_SF_GENERAL;
 //   GENERAL = true : the leaf needs prims / chains / materials / textures (a texture to evaluate, a wrapper chain to replay): k_wf_shade.
+// A record k_wf_shade must shade in full: marked so, or an albedo-pending record (RTC_SF_TEXTURED) under integrator 0, whose weights read the albedo
+__device__ __forceinline__ bool wf_is_general(const RenderParams &P, uint32_t meta) {
+    return (meta & RTC_SF_GENERAL) || ((meta & RTC_SF_TEXTURED) && P.integrator == 0);
+}
 template <bool NOISE, bool GENERAL>
 __device__ __forceinline__ bool wf_shade_entry(const SceneT<float> &sc, const CameraT<float> &cam, const RenderParams &P, const WfBuffers &B, int slot,
                                                int px, int py, const float4 &o, const float4 &d, const float4 &tm, float hit_t, int hslot, SmallShade sh, unsigned char &key) {
@@ -108,6 +112,7 @@ __device__ __forceinline__ bool wf_shade_entry(const SceneT<float> &sc, const Ca
     ps.T = f3mk(d.w, tm.x, tm.y); ps.L = f3mk(0, 0, 0);
     const uint32_t pixel = (uint32_t)m.w;
     bool died = false, have_sum = false;
+    bool albedo_pending = false;                                     // the hit shaded last was a RTC_SF_TEXTURED record and its path goes on
     float4 s4 = make_float4(0, 0, 0, 0);
     // One trip = one hit shaded.  A path that ends here starts the slot's next sample, and the closest hit of that sample's camera ray is
     // already known (B.phit, k_wf_primary: the camera rays of a render are traced up front, in coherent waves of their own) -- so the
@@ -137,6 +142,7 @@ __device__ __forceinline__ bool wf_shade_entry(const SceneT<float> &sc, const Ca
                 MaterialT<float> mat; mat.type = (int)(sh.meta & 0xffu); mat.tex = -1; mat.albedo[0] = sh.rgb[0]; mat.albedo[1] = sh.rgb[1]; mat.albedo[2] = sh.rgb[2]; mat.param = sh.param;
                 status = shade_hit_mat<false>(sc, ps, rec, mat, true, P.integrator, P.light_weight, xi);
                 m.z = (sh.meta & RTC_SF_MEDIUM) ? -1 : hslot;
+                albedo_pending = (sh.meta & RTC_SF_TEXTURED) != 0;
             } else {
                 const PrimT<float> p = sc.prims[sc.leaf_prims[hslot]];
                 const MaterialT<float> &mat = sc.materials[p.mat];
@@ -154,6 +160,7 @@ __device__ __forceinline__ bool wf_shade_entry(const SceneT<float> &sc, const Ca
             if (!have_sum) { s4 = B.sum[slot]; have_sum = true; }
             s4.x += ps.L.x; s4.y += ps.L.y; s4.z += ps.L.z;
         }
+        albedo_pending = false;                                      // (that path is over: nothing reads its throughput any more)
         m.x += B.layers;                                             // this slot's next sample
         if (m.x >= P.s_end) { died = true; break; }
         ps.ray = primary_ray(cam, P, pixel, px, py, (uint32_t)m.x);
@@ -164,16 +171,17 @@ __device__ __forceinline__ bool wf_shade_entry(const SceneT<float> &sc, const Ca
         if (!GENERAL) {
             sh.meta = 0;
             if (hslot >= 0) sh = sc.leaf_shade[hslot];
-            if (sh.meta & RTC_SF_GENERAL) {                          // k_wf_shade's: park the hit and its regrouping key next to the new path's state
+            if (wf_is_general(P, sh.meta)) {                         // k_wf_shade's: park the hit and its regrouping key next to the new path's state
                 B.hit[slot] = ph;
                 key = (unsigned char)((sh.meta >> 16) & 31u);
                 break;
             }
-        } else if (hslot >= 0 && !(sc.leaf_shade[hslot].meta & RTC_SF_GENERAL)) break;   // a leaf that extend's tail shades from its record: left to the
+        } else if (hslot >= 0 && !wf_is_general(P, sc.leaf_shade[hslot].meta)) break;   // a leaf that extend's tail shades from its record: left to the
                                                                      // next extend launch (which takes the known hit and traces nothing), so that a hit is
                                                                      // shaded by the same code whichever kernel started its path
     }
     if (have_sum) B.sum[slot] = s4;
+    if (!GENERAL && albedo_pending && !died) key = (unsigned char)(RTC_WF_KEY_ALBEDO | ((sh.meta >> 16) & 31u));   // k_wf_shade multiplies the throughput written below
     if (!died) {
         B.ro[slot] = make_float4(ps.ray.o.x, ps.ray.o.y, ps.ray.o.z, ps.ray.time);
         B.rd[slot] = make_float4(ps.ray.d.x, ps.ray.d.y, ps.ray.d.z, ps.T.x);
@@ -202,7 +210,7 @@ __device__ __forceinline__ bool wf_extend_tail(const SceneT<float> &sc, const Ca
                                                int px, int py, const float4 &o, const float4 &d, const float4 &tm, const HitS &h, unsigned char &key) {
     SmallShade sh; sh.meta = 0;
     if (h.slot >= 0) sh = sc.leaf_shade[h.slot];
-    if (sh.meta & RTC_SF_GENERAL) {                                  // k_wf_shade's: park the hit and its regrouping key
+    if (wf_is_general(P, sh.meta)) {                                 // k_wf_shade's: park the hit and its regrouping key
         B.hit[slot] = make_float2(h.t, __int_as_float(h.slot));
         key = (unsigned char)((sh.meta >> 16) & 31u);
         return false;
@@ -473,7 +481,7 @@ __global__ void __launch_bounds__(wf_shade_block(NOISE)) __attribute__((amdgpu_w
     const unsigned n_list = B.counters[WF_NLIST]; const int cur = (int)B.counters[WF_CUR];
     __shared__ unsigned q_index[QCAP];
     __shared__ unsigned char q_key[QCAP];
-    __shared__ unsigned wave_count[N / 64], key_count[32], key_start[32];
+    __shared__ unsigned wave_count[N / 64], key_count[64], key_start[64];
     __shared__ unsigned sorted_index[N];
     __shared__ float noise_vec[NOISE ? 768 * kWfShadeNoiseSlots : 1];
     __shared__ int noise_perm[NOISE ? 768 * kWfShadeNoiseSlots : 1];
@@ -509,29 +517,38 @@ __global__ void __launch_bounds__(wf_shade_block(NOISE)) __attribute__((amdgpu_w
             for (unsigned w = 0; w < N / 64; ++w) { const unsigned n = wave_count[w]; before += w < wave ? n : 0u; total += n; }
 #pragma unroll
             for (unsigned j = 0; j < KPT; ++j)
-                if (parked[j]) { const unsigned at = (q_head + q_n + before + pos[j]) & (QCAP - 1); q_index[at] = i0 + j; q_key[at] = (unsigned char)((keys >> (8 * j)) & 31u); }
+                if (parked[j]) { const unsigned at = (q_head + q_n + before + pos[j]) & (QCAP - 1); q_index[at] = i0 + j; q_key[at] = (unsigned char)((keys >> (8 * j)) & 63u); }
             q_n += total;                                            // <= (N - 1) + 4 N < QCAP
         }
         while (q_n >= N || (flush && q_n > 0)) {
             const unsigned take = q_n < N ? q_n : N;
-            if (tid < 32) key_count[tid] = 0;
+            if (tid < 64) key_count[tid] = 0;
             __syncthreads();                                         // (also: the queue entries written above are visible)
             const unsigned at = (q_head + tid) & (QCAP - 1);
             const unsigned key = tid < take ? q_key[at] : 0u;
             const unsigned index = tid < take ? q_index[at] : 0u;
             const unsigned rank = tid < take ? atomicAdd(&key_count[key], 1u) : 0u;
             __syncthreads();
-            if (tid == 0) { unsigned acc = 0; for (int k = 0; k < 32; ++k) { key_start[k] = acc; acc += key_count[k]; } }
+            if (tid == 0) { unsigned acc = 0; for (int k = 0; k < 64; ++k) { key_start[k] = acc; acc += key_count[k]; } }
             __syncthreads();
-            if (tid < take) sorted_index[key_start[key] + rank] = index;
+            if (tid < take) sorted_index[key_start[key] + rank] = index | ((key & (unsigned)RTC_WF_KEY_ALBEDO) << 26);   // (list positions are < 2^25; bit 31 = albedo only)
             q_head = (q_head + take) & (QCAP - 1); q_n -= take;
             __syncthreads();
             bool died = false;
             if (tid < take) {
                 const WfArgs &t = wf_args_again(c);                  // scene, camera and render parameters: read here, not held across the scan
-                const unsigned i = sorted_index[tid];
+                const unsigned i = sorted_index[tid] & 0x7fffffffu;
+                const bool albedo_only = (sorted_index[tid] >> 31) != 0;
                 const int slot = t.B.active[cur][i];
                 const float4 o = t.B.ro[slot], d = t.B.rd[slot], tm = t.B.tm[slot];
+                if (albedo_only) {                                   // RTC_SF_TEXTURED: extend's tail has shaded the hit with albedo 1; the new ray starts at the hit point, on the textured leaf
+                    const SmallShade sh = t.sc.leaf_shade[__float_as_int(tm.w)];
+                    f3 val;
+                    if (noise_in_lds) { SceneT<float> sc = t.sc; sc.perlin_vec = noise_vec; sc.perlin_perm = noise_perm; val = texture_value<NOISE>(sc, __float_as_int(sh.param), 0.0f, 0.0f, f3mk(o.x, o.y, o.z)); }
+                    else val = texture_value<NOISE>(t.sc, __float_as_int(sh.param), 0.0f, 0.0f, f3mk(o.x, o.y, o.z));
+                    t.B.rd[slot] = make_float4(d.x, d.y, d.z, d.w * val.x);
+                    t.B.tm[slot] = make_float4(tm.x * val.y, tm.y * val.z, tm.z, tm.w);
+                } else {
                 int px, py, layer; slot_pixel(t.P, t.B, slot, px, py, layer);
                 const float2 hh = t.B.hit[slot];
                 SmallShade none; none.meta = 0;
@@ -542,6 +559,7 @@ __global__ void __launch_bounds__(wf_shade_block(NOISE)) __attribute__((amdgpu_w
                 }
                 else died = wf_shade_entry<NOISE, true>(t.sc, t.cam, t.P, t.B, slot, px, py, o, d, tm, hh.x, __float_as_int(hh.y), none, no_key);
                 if (died) t.B.active[cur][i] = -1;                   // stays in the list as a hole until the next compaction
+                }
             }
             { const unsigned long long dm = __builtin_amdgcn_ballot_w64(died); if (lane == 0) wave_report(B, blockIdx.x * (N / 64) + wave, 0ull, dm); }
             __syncthreads();                                         // sorted_index is free again

@@ -152,7 +152,7 @@ template <typename R> hipError_t upload_tables(const FlatScene &fs, DeviceTables
     v.bvh_stack = fs.bvh_depth < 1 ? 1 : fs.bvh_depth;   // one entry per level; flatten / load refuse trees deeper than RTC_BVH_MAX_DEPTH: nothing is clamped here
     v.n_media = fs.n_media;
     v.n_bleaves = (int)fs.bleaves.size();
-    v.n_general = 0; for (const SmallShade &sh : fs.leaf_shade) v.n_general += (sh.meta & RTC_SF_GENERAL) != 0;
+    v.n_general = 0; for (const SmallShade &sh : fs.leaf_shade) v.n_general += (sh.meta & (RTC_SF_GENERAL | RTC_SF_TEXTURED)) != 0;
     v.leaf_kinds = fs.leaf_kinds;
     v.tex_kinds = 0; for (const auto &t : fs.textures) v.tex_kinds |= 1 << t.type;
     v.n_perlin = (int)(fs.perlin_perm.size() / 768);

@@ -97,7 +97,7 @@ template <typename R> struct SceneT {
     int n_perlin;            // noise slots behind perlin_vec / perlin_perm
     int media_kind;          // BVH leaves: 0 no media, 1 sphere-bounded media only (BLeaf carries them), 2 general boundaries
     int n_bleaves;           // records of bleaves (one per leaf slot)
-    int n_general;           // leaf slots whose shading record is marked RTC_SF_GENERAL (0: the wavefront never launches k_wf_shade)
+    int n_general;           // leaf slots whose shading record is marked RTC_SF_GENERAL or RTC_SF_TEXTURED (0: the wavefront never launches k_wf_shade)
     R background[3];
 };
 // ---- small-scene pack (FP32 production path for scenes of <= 64 rect/sphere leaves with solid textures) --------------
@@ -122,8 +122,11 @@ enum { RTC_SF_FORCED_FRONT = 1u << 8, RTC_SF_FLIP = 1u << 9, RTC_SF_SPHERE = 1u 
        // BVH leaf_shade only:
        RTC_SF_GENERAL = 1u << 11,     // not resolvable here (a texture to evaluate, a wrapper chain to replay) -> prims / materials / textures in k_wf_shade
        RTC_SF_MOVING = 1u << 12,      // moving sphere: centre = g[0..2] + pad[0..2] * time (never glass: pad is the glass constants' place)
+       RTC_SF_TEXTURED = 1u << 14,    // lambertian with a noise texture on a plain sphere: the record shades the hit with albedo 1 (rgb) and the texture index (param, int
+                                      // bits) is left for k_wf_shade, which multiplies the slot's throughput by the texture's value at the new ray's origin -- integrators
+                                      // 1 and 2, where the scattered ray does not depend on the albedo (under integrator 0 the record counts as RTC_SF_GENERAL)
        RTC_SF_MEDIUM = 1u << 13 };    // constant medium (isotropic phase function, no surface); bits 16-20: regrouping key of k_wf_shade = material type * 4 + texture type
-enum { RTC_WF_KEY_DONE = 255 };       // WfBuffers::key of an entry extend has shaded itself
+enum { RTC_WF_KEY_DONE = 255, RTC_WF_KEY_ALBEDO = 32 };   // WfBuffers::key of an entry extend has shaded itself; bit of an entry that waits for its albedo only (RTC_SF_TEXTURED)
 struct alignas(64) SmallPair { float f[16]; };
 struct alignas(32) SmallGroup { int xform, first, n_xy, n_xz, n_yz, box, rot_y, pad2; };   // box >= 0: SmallBox of this space, tested before the pairs;
                                                                                        // rot_y: the space's map leaves y alone up to a shift (m[1] = m[3] = m[5] = m[7] = 0, m[4] = 1)

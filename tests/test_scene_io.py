@@ -66,7 +66,7 @@ def test_file_layout_is_what_the_header_says(rtc, tmp_path):
         sc.save(path)
         blob = open(path, "rb").read()
         magic, version, n_sections, payload, crc = struct.unpack_from("<8sIIQI", blob, 0)
-        assert magic == b"RTCSCENE" and version == 3 and payload == len(blob) - 64 and crc == zlib.crc32(blob[64:]) & 0xFFFFFFFF
+        assert magic == b"RTCSCENE" and version == 4 and payload == len(blob) - 64 and crc == zlib.crc32(blob[64:]) & 0xFFFFFFFF
         secs = _sections(blob)
         assert len(secs) == n_sections and secs["prims"][2] == sc.num_prims() and secs["nodes"][2] == sc.bvh_info()["nodes"]
         assert secs["nodes"][1] == 64 and secs["bleaves"][1] == 64 and secs["leaf_shade"][1] == 48

@@ -568,7 +568,7 @@ void build_leaf_shade(FlatScene &fs) {
             S.rgb[0] = S.rgb[1] = S.rgb[2] = 1.0f; S.param = (float)m.param; S.pad[0] = (float)(1.0 / m.param);
             const double r = (1.0 - m.param) / (1.0 + m.param); S.pad[1] = (float)(r * r);
         }
-        else if (m.type == RTC_MAT_LAMBERTIAN && m.tex >= 0 && fs.textures[m.tex].type == RTC_TEX_NOISE && p.type == RTC_PRIM_SPHERE) {   // albedo left to k_wf_shade (RTC_SF_TEXTURED)
+        else if (m.type == RTC_MAT_LAMBERTIAN && m.tex >= 0 && fs.textures[m.tex].type != RTC_TEX_SOLID && p.type == RTC_PRIM_SPHERE) {   // noise, image, checker: albedo left to k_wf_shade (RTC_SF_TEXTURED)
             S.rgb[0] = S.rgb[1] = S.rgb[2] = 1.0f; std::memcpy(&S.param, &m.tex, sizeof(int)); S.meta |= RTC_SF_TEXTURED;
         }
         else if (m.tex < 0 || fs.textures[m.tex].type != RTC_TEX_SOLID) general = true;

@@ -148,7 +148,7 @@ bool validate_flat_scene(const FlatScene &fs, std::string &err) {
         const size_t nl = fs.leaf_prims.size();
         REQ(fs.bleaves.size() == nl && fs.leaf_shade.size() == nl, "leaf tables differ in length");
         for (const SmallShade &sh : fs.leaf_shade)
-            if (sh.meta & RTC_SF_TEXTURED) { int t; std::memcpy(&t, &sh.param, sizeof t); REQ(t >= 0 && (size_t)t < fs.textures.size() && fs.textures[t].type == RTC_TEX_NOISE, "textured shading record without its texture"); }
+            if (sh.meta & RTC_SF_TEXTURED) { int t; std::memcpy(&t, &sh.param, sizeof t); REQ(t >= 0 && (size_t)t < fs.textures.size() && fs.textures[t].type != RTC_TEX_SOLID, "textured shading record without its texture"); }
         for (const int p : fs.leaf_prims) REQ(in(p, fs.prims.size()), "a leaf slot points outside the primitive table");
         std::vector<char> box_start(nl, 0);
         for (const int s : fs.box_slots) { REQ(run_in(s, 6, nl), "a box record leaves the leaf table"); box_start[(size_t)s] = 1; }

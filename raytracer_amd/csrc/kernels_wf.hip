@@ -543,9 +543,11 @@ __global__ void __launch_bounds__(wf_shade_block(NOISE)) __attribute__((amdgpu_w
                 const float4 o = t.B.ro[slot], d = t.B.rd[slot], tm = t.B.tm[slot];
                 if (albedo_only) {                                   // RTC_SF_TEXTURED: extend's tail has shaded the hit with albedo 1; the new ray starts at the hit point, on the textured leaf
                     const SmallShade sh = t.sc.leaf_shade[__float_as_int(tm.w)];
+                    const f3 p = f3mk(o.x, o.y, o.z);
+                    float u, v; sphere_uv<float>((p - f3mk(sh.g[0], sh.g[1], sh.g[2])) * sh.g[3], u, v);   // hittable.c:381-386 on the outward normal (an image texture reads them)
                     f3 val;
-                    if (noise_in_lds) { SceneT<float> sc = t.sc; sc.perlin_vec = noise_vec; sc.perlin_perm = noise_perm; val = texture_value<NOISE>(sc, __float_as_int(sh.param), 0.0f, 0.0f, f3mk(o.x, o.y, o.z)); }
-                    else val = texture_value<NOISE>(t.sc, __float_as_int(sh.param), 0.0f, 0.0f, f3mk(o.x, o.y, o.z));
+                    if (noise_in_lds) { SceneT<float> sc = t.sc; sc.perlin_vec = noise_vec; sc.perlin_perm = noise_perm; val = texture_value<NOISE>(sc, __float_as_int(sh.param), u, v, p); }
+                    else val = texture_value<NOISE>(t.sc, __float_as_int(sh.param), u, v, p);
                     t.B.rd[slot] = make_float4(d.x, d.y, d.z, d.w * val.x);
                     t.B.tm[slot] = make_float4(tm.x * val.y, tm.y * val.z, tm.z, tm.w);
                 } else {

@@ -122,7 +122,7 @@ enum { RTC_SF_FORCED_FRONT = 1u << 8, RTC_SF_FLIP = 1u << 9, RTC_SF_SPHERE = 1u 
        // BVH leaf_shade only:
        RTC_SF_GENERAL = 1u << 11,     // not resolvable here (a texture to evaluate, a wrapper chain to replay) -> prims / materials / textures in k_wf_shade
        RTC_SF_MOVING = 1u << 12,      // moving sphere: centre = g[0..2] + pad[0..2] * time (never glass: pad is the glass constants' place)
-       RTC_SF_TEXTURED = 1u << 14,    // lambertian with a noise texture on a plain sphere: the record shades the hit with albedo 1 (rgb) and the texture index (param, int
+       RTC_SF_TEXTURED = 1u << 14,    // lambertian with a noise, image or checker texture on a plain sphere: the record shades the hit with albedo 1 (rgb) and the texture index (param, int
                                       // bits) is left for k_wf_shade, which multiplies the slot's throughput by the texture's value at the new ray's origin -- integrators
                                       // 1 and 2, where the scattered ray does not depend on the albedo (under integrator 0 the record counts as RTC_SF_GENERAL)
        RTC_SF_MEDIUM = 1u << 13 };    // constant medium (isotropic phase function, no surface); bits 16-20: regrouping key of k_wf_shade = material type * 4 + texture type
